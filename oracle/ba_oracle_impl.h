@@ -1,0 +1,771 @@
+/*
+ * ba_oracle_impl.h -- TEST INFRASTRUCTURE ONLY (CPU oracle), never the product path.
+ *
+ * Plain-C restatement of the Levenberg-Marquardt bundle-adjustment hot path of
+ * jasvob/BundleAdjustment_Benchmarks.  Included twice by ba_oracle.c, once with
+ * S = double (suffix _f64) and once with S = float (suffix _f32), mirroring the
+ * reference's `typedef double Scalar;` switch (src/BATypeUtils.h:6-7).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or recorded
+ * output, and cannot be compiled here (private Eigen/QRKit fork + SuiteSparse
+ * absent).  This oracle is pinned only by (1) the two BAL data
+ * files the reference ships, (2) finite-difference / mpmath checks of the
+ * Jacobian, (3) an independent scipy sparse solve of (J'J + lambda I) dx = -J'r
+ * (tests/test_oracle.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call
+ * into this file.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).
+ */
+
+/* ---- per-observation geometry --------------------------------------------------------- */
+
+/* Camera state layout (15 scalars): R row-major [0..8], T [9..11], f=K(0,0) [12], k1 [13], k2 [14].
+ * The reference holds K,R,T,K^-1,R^T,centre per camera (CameraMatrix.h:72-76); only these 15 are state. */
+
+/* Math::createRotationMatrixRodrigues, MathUtils.h:66-82 (theta <= 1e-6 -> identity). */
+static void FN(rodrigues)(const S *om, S *R)
+{
+    const S theta = SQRT(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    if (FABS(theta) > (S)1e-6) {
+        /* J = [om]x (MathUtils.h:13-21), J2 = J*J */
+        S J[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+        S J2[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                S a = 0;
+                for (int k = 0; k < 3; k++) a += J[i * 3 + k] * J[k * 3 + j];
+                J2[i * 3 + j] = a;
+            }
+        const S c1 = SIN(theta) / theta;
+        const S c2 = ((S)1.0 - COS(theta)) / (theta * theta);
+        for (int i = 0; i < 9; i++) R[i] = R[i] + c1 * J[i] + c2 * J2[i];
+    }
+}
+
+/* bundle_adjustment_large.cpp:81-99: K00=K11=-f/avg_focal (avg_focal=1), R=Rodrigues(om),
+ * distortion (k1 f^2, k2 f^4). cams9 = [om(3), T(3), f, k1, k2] per camera as in the BAL file. */
+void FN(ora_init_cams)(int N, const double *cams9, S *cam15)
+{
+    for (int i = 0; i < N; i++) {
+        const double *c = cams9 + 9 * (size_t)i;
+        S *o = cam15 + 15 * (size_t)i;
+        S om[3] = {(S)c[0], (S)c[1], (S)c[2]};
+        FN(rodrigues)(om, o);
+        o[9] = (S)c[3]; o[10] = (S)c[4]; o[11] = (S)c[5];
+        const S f = (S)c[6], k1 = (S)c[7], k2 = (S)c[8];
+        const S f2 = f * f;
+        o[12] = -f / (S)1.0;
+        o[13] = k1 * f2;
+        o[14] = k2 * f2 * f2;
+    }
+}
+
+/* BAFunctor::psi / psi_weight, BAFunctor.h:147-148 */
+static inline S FN(psi)(S tau2, S r2) { return (r2 < tau2) ? r2 * ((S)2.0 - r2 / tau2) / (S)4.0 : tau2 / (S)4.0; }
+static inline S FN(psi_weight)(S tau2, S r2) { S w = (S)1.0 - r2 / tau2; return w > (S)0.0 ? w : (S)0.0; }
+
+#define EPS_PSI ((S)1e-15) /* BAFunctor.h:159 */
+
+/* BAFunctor::projectPoint, BAFunctor.h:151-156 (+ CameraMatrix.cpp:259-261, DistortionFunction.cpp:14-23) */
+static inline void FN(project)(const S *cam, const S *X, S *q)
+{
+    const S XX0 = cam[0] * X[0] + cam[1] * X[1] + cam[2] * X[2] + cam[9];
+    const S XX1 = cam[3] * X[0] + cam[4] * X[1] + cam[5] * X[2] + cam[10];
+    const S XX2 = cam[6] * X[0] + cam[7] * X[1] + cam[8] * X[2] + cam[11];
+    const S xu0 = XX0 / XX2, xu1 = XX1 / XX2;
+    const S r2 = xu0 * xu0 + xu1 * xu1;
+    const S r4 = r2 * r2;
+    const S kr = 1 + cam[13] * r2 + cam[14] * r4;
+    q[0] = cam[12] * (kr * xu0);
+    q[1] = cam[12] * (kr * xu1);
+}
+
+/* BAFunctor::E_pos, BAFunctor.h:160-178.  fvec is obs-major interleaved (2i, 2i+1).
+ * Returns the energy fvec.squaredNorm() (BacktrackLevMarqQRChol.h:261). */
+S FN(ora_residuals)(int N, int M, int K, const S *cam15, const S *pts, const int *cam_idx, const int *pt_idx,
+                    const S *meas, S tau, S *fvec)
+{
+    (void)N; (void)M;
+    const S tau2 = tau * tau;
+    S energy = 0;
+    for (int i = 0; i < K; i++) {
+        S q[2];
+        FN(project)(cam15 + 15 * (size_t)cam_idx[i], pts + 3 * (size_t)pt_idx[i], q);
+        const S r0 = q[0] - meas[2 * (size_t)i], r1 = q[1] - meas[2 * (size_t)i + 1];
+        const S r2 = r0 * r0 + r1 * r1;
+        const S sqrt_psi = SQRT(FN(psi)(tau2, r2));
+        const S nr = SQRT(r2);
+        const S rnorm_r = (S)1.0 / (EPS_PSI > nr ? EPS_PSI : nr);
+        const S e0 = r0 * sqrt_psi * rnorm_r, e1 = r1 * sqrt_psi * rnorm_r;
+        if (fvec) { fvec[2 * (size_t)i] = e0; fvec[2 * (size_t)i + 1] = e1; }
+        energy += e0 * e0 + e1 * e1;
+    }
+    return energy;
+}
+
+/* BAFunctor::dE_pos, BAFunctor.h:181-297 (+ poseDerivatives :126-142, DistortionFunction.cpp:25-51).
+ * Jc: K blocks of 2x9 row-major, camera columns ordered [T(3), omega(3), f, k1, k2] (:186-191,265-284);
+ * Jp: K blocks of 2x3 row-major (:287-292). */
+void FN(ora_jacobian)(int N, int M, int K, const S *cam15, const S *pts, const int *cam_idx, const int *pt_idx,
+                      const S *meas, S tau, S *Jc, S *Jp)
+{
+    (void)N; (void)M;
+    const S tau2 = tau * tau;
+    for (int i = 0; i < K; i++) {
+        const S *cam = cam15 + 15 * (size_t)cam_idx[i];
+        const S *X = pts + 3 * (size_t)pt_idx[i];
+        /* poseDerivatives: XX = R X + T ; d_dRT = [I | -[XX - T]x] ; d_dX = R */
+        const S RX0 = cam[0] * X[0] + cam[1] * X[1] + cam[2] * X[2];
+        const S RX1 = cam[3] * X[0] + cam[4] * X[1] + cam[5] * X[2];
+        const S RX2 = cam[6] * X[0] + cam[7] * X[1] + cam[8] * X[2];
+        const S XX0 = RX0 + cam[9], XX1 = RX1 + cam[10], XX2 = RX2 + cam[11];
+        const S v0 = XX0 - cam[9], v1 = XX1 - cam[10], v2 = XX2 - cam[11];
+        /* -[v]x */
+        const S mJ[9] = {0, v2, -v1, -v2, 0, v0, v1, -v0, 0};
+        const S xu0 = XX0 / XX2, xu1 = XX1 / XX2;
+        const S r2u = xu0 * xu0 + xu1 * xu1, r4u = r2u * r2u;
+        const S k1 = cam[13], k2 = cam[14], f = cam[12];
+        const S kr = 1 + k1 * r2u + k2 * r4u;
+        const S xd0 = kr * xu0, xd1 = kr * xu1;
+        /* dxu_dXX (:219-221) */
+        const S a00 = (S)1.0 / XX2, a02 = -XX0 / (XX2 * XX2);
+        const S a11 = (S)1.0 / XX2, a12 = -XX1 / (XX2 * XX2);
+        /* dxd_dxu (DistortionFunction.cpp:38-51) */
+        const S dkr = 2 * k1 + 4 * k2 * r2u;
+        const S d00 = kr + xu0 * xu0 * dkr, d01 = xu0 * xu1 * dkr, d11 = kr + xu1 * xu1 * dkr;
+        /* dp_dxu = diag(f,f) * dxd_dxu ; dp_dXX = dp_dxu * dxu_dXX (:223-225) */
+        const S p00 = f * d00, p01 = f * d01, p10 = f * d01, p11 = f * d11;
+        S dpX[6]; /* 2x3 */
+        dpX[0] = p00 * a00; dpX[1] = p01 * a11; dpX[2] = p00 * a02 + p01 * a12;
+        dpX[3] = p10 * a00; dpX[4] = p11 * a11; dpX[5] = p10 * a02 + p11 * a12;
+        /* outer derivative of the psi residual (:227-242) */
+        const S q0 = f * xd0, q1 = f * xd1;
+        const S r0 = q0 - meas[2 * (size_t)i], r1 = q1 - meas[2 * (size_t)i + 1];
+        const S r2 = r0 * r0 + r1 * r1;
+        const S W = FN(psi_weight)(tau2, r2);
+        const S sqrt_psi = SQRT(FN(psi)(tau2, r2));
+        const S rsqrt_psi = (S)1.0 / (EPS_PSI > sqrt_psi ? EPS_PSI : sqrt_psi);
+        const S rcp_r2 = (S)1.0 / (EPS_PSI > r2 ? EPS_PSI : r2);
+        const S nr = SQRT(r2);
+        const S rnorm_r = (S)1.0 / (EPS_PSI > nr ? EPS_PSI : nr);
+        const S rr00 = r0 * r0 * rnorm_r, rr01 = r0 * r1 * rnorm_r, rr11 = r1 * r1 * rnorm_r;
+        const S c1 = W / (S)2.0 * rsqrt_psi, c2 = sqrt_psi * rcp_r2;
+        const S o00 = c1 * rr00 + c2 * (nr - rr00);
+        const S o01 = c1 * rr01 + c2 * ((S)0 - rr01);
+        const S o11 = c1 * rr11 + c2 * (nr - rr11);
+        /* Jblock (2x12): [0..5]=dp_dXX*d_dRT, [6]=xd, [7,8]=f*d xd/d(k1,k2), [9..11]=dp_dXX*R (:244-258) */
+        S Jb[24];
+        for (int r = 0; r < 2; r++) {
+            const S *d = dpX + 3 * r;
+            S *o = Jb + 12 * r;
+            o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
+            for (int c = 0; c < 3; c++) o[3 + c] = d[0] * mJ[c] + d[1] * mJ[3 + c] + d[2] * mJ[6 + c];
+            for (int c = 0; c < 3; c++) o[9 + c] = d[0] * cam[c] + d[1] * cam[3 + c] + d[2] * cam[6 + c];
+        }
+        Jb[6] = xd0; Jb[12 + 6] = xd1;
+        Jb[7] = f * (xu0 * r2u); Jb[8] = f * (xu0 * r4u);
+        Jb[12 + 7] = f * (xu1 * r2u); Jb[12 + 8] = f * (xu1 * r4u);
+        /* Jblock = outer_deriv * Jblock (:261) */
+        S *jc = Jc + 18 * (size_t)i, *jp = Jp + 6 * (size_t)i;
+        for (int c = 0; c < 12; c++) {
+            const S t0 = o00 * Jb[c] + o01 * Jb[12 + c];
+            const S t1 = o01 * Jb[c] + o11 * Jb[12 + c];
+            if (c < 9) { jc[c] = t0; jc[9 + c] = t1; }
+            else { jp[c - 9] = t0; jp[3 + c - 9] = t1; }
+        }
+    }
+}
+
+/* BAFunctor::update_params, BAFunctor.h:299-342.  dx layout = Jacobian column order:
+ * 3M point coordinates first, then per camera [T(3), omega(3), f, k1, k2]. */
+void FN(ora_retract)(int N, int M, const S *cam_in, const S *pts_in, const S *dx, S *cam_out, S *pts_out)
+{
+    const S *dc = dx + 3 * (size_t)M;
+    for (int i = 0; i < N; i++) {
+        const S *c = cam_in + 15 * (size_t)i;
+        S *o = cam_out + 15 * (size_t)i;
+        const S *p = dc + 9 * (size_t)i;
+        S dR[9], Rn[9];
+        FN(rodrigues)(p + 3, dR);
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) {
+                S a = 0;
+                for (int k = 0; k < 3; k++) a += dR[r * 3 + k] * c[k * 3 + q];
+                Rn[r * 3 + q] = a;
+            }
+        for (int k = 0; k < 9; k++) o[k] = Rn[k];
+        o[9] = c[9] + p[0]; o[10] = c[10] + p[1]; o[11] = c[11] + p[2];
+        o[12] = c[12] + p[6];
+        o[13] = c[13] + p[7];
+        o[14] = c[14] + p[8];
+    }
+    for (size_t i = 0; i < 3 * (size_t)M; i++) pts_out[i] = pts_in[i] + dx[i];
+}
+
+/* Utils::showErrorStatistics + showObjective, Utils.h:10-68 (CameraMatrix::projectPoint(dist,X),
+ * CameraMatrix.cpp:225-236).  out = {mean reprojection error, inlier mean error, nInliers, objective}.
+ * Quirk kept: showObjective feeds the NORM (not squared) into Utils::psi (Utils.h:61-62). */
+void FN(ora_stats)(int N, int M, int K, const S *cam15, const S *pts, const int *cam_idx, const int *pt_idx,
+                   const S *meas, S tau, double *out4)
+{
+    (void)N; (void)M;
+    const S tau2 = tau * tau, tau4 = tau2 * tau2;
+    S mean = 0, inl = 0, obj = 0;
+    int nin = 0;
+    for (int k = 0; k < K; k++) {
+        S q[2];
+        FN(project)(cam15 + 15 * (size_t)cam_idx[k], pts + 3 * (size_t)pt_idx[k], q);
+        const S d0 = q[0] - meas[2 * (size_t)k], d1 = q[1] - meas[2 * (size_t)k + 1];
+        const S err = SQRT(d0 * d0 + d1 * d1);
+        mean += err;
+        if (err <= tau) { nin++; inl += err; }
+        const S r2 = err; /* sic */
+        const S r4 = r2 * r2;
+        obj += (r2 < tau2) ? r2 * ((S)3.0 - (S)3.0 * r2 / tau2 + r4 / tau4) / (S)6.0 : tau2 / (S)6.0;
+    }
+    out4[0] = (double)(mean / K);
+    out4[1] = (double)(inl / nin);
+    out4[2] = (double)nin;
+    out4[3] = (double)obj;
+}
+
+/* ---- linear algebra of one LM trial --------------------------------------------------- */
+
+/* Dense LDL^T, lower triangle, column-major n x n with leading dimension n, in place:
+ * strictly-lower part <- L (unit diagonal implied), diagonal <- D.  Stands in for
+ * Eigen::SimplicialLDLT on the (block-dense) reduced camera matrix
+ * (BAFunctor.h:106, BacktrackLevMarqQRChol.h:339; BacktrackLevMarqCholesky.h:156,278).
+ * No pivoting, no sqrt: survives small negative pivots like SimplicialLDLT does. */
+static void FN(dense_ldlt)(int n, S *A)
+{
+    S *w = (S *)malloc(sizeof(S) * (size_t)n);
+    for (int j = 0; j < n; j++) {
+        /* left-looking: w[k] = L[j][k]*D[k] */
+        S d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) {
+            w[k] = A[(size_t)k * n + j] * A[(size_t)k * n + k];
+            d -= A[(size_t)k * n + j] * w[k];
+        }
+        A[(size_t)j * n + j] = d;
+        S *col = A + (size_t)j * n;
+        for (int k = 0; k < j; k++) {
+            const S wk = w[k];
+            const S *ck = A + (size_t)k * n;
+            for (int i = j + 1; i < n; i++) col[i] -= ck[i] * wk;
+        }
+        const S inv = (S)1.0 / d;
+        for (int i = j + 1; i < n; i++) col[i] *= inv;
+    }
+    free(w);
+}
+
+static void FN(dense_ldlt_solve)(int n, const S *A, S *b)
+{
+    for (int j = 0; j < n; j++) {
+        const S bj = b[j];
+        const S *col = A + (size_t)j * n;
+        for (int i = j + 1; i < n; i++) b[i] -= col[i] * bj;
+    }
+    for (int j = 0; j < n; j++) b[j] /= A[(size_t)j * n + j];
+    for (int j = n - 1; j >= 0; j--) {
+        const S *col = A + (size_t)j * n;
+        S a = b[j];
+        for (int i = j + 1; i < n; i++) a -= col[i] * b[i];
+        b[j] = a;
+    }
+}
+
+/* Dense Householder QR solve of min || A x - b ||, A is m x n column-major (ld m), overwritten.
+ * Stands in for QRKit's DenseBlockedThinQR on the lower-right block (BAFunctor.h:101; README.md:14). */
+static void FN(dense_qr_solve)(int m, int n, S *A, S *b, S *x)
+{
+    for (int j = 0; j < n; j++) {
+        S *col = A + (size_t)j * m;
+        S xn = 0;
+        for (int i = j + 1; i < m; i++) xn += col[i] * col[i];
+        const S alpha = col[j];
+        if (xn == 0) continue; /* H = I */
+        S beta = SQRT(alpha * alpha + xn);
+        if (alpha > 0) beta = -beta;
+        const S tau = (beta - alpha) / beta;
+        const S sc = (S)1.0 / (alpha - beta);
+        for (int i = j + 1; i < m; i++) col[i] *= sc;
+        col[j] = beta;
+        for (int c = j + 1; c <= n; c++) {
+            S *cc = (c < n) ? A + (size_t)c * m : b;
+            S w = cc[j];
+            for (int i = j + 1; i < m; i++) w += col[i] * cc[i];
+            w *= tau;
+            cc[j] -= w;
+            for (int i = j + 1; i < m; i++) cc[i] -= col[i] * w;
+        }
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        S a = b[j];
+        for (int c = j + 1; c < n; c++) a -= A[(size_t)c * m + j] * x[c];
+        x[j] = a / A[(size_t)j * m + j];
+    }
+}
+
+/* Workspace of the per-point elimination shared by all three solver symbols:
+ *   Z[i]    9x3 per observation (row-major): CHOLESKY  Z = A^T B L^-T     (W L^-T)
+ *                                            QR        Z = R12_i^T = A^T Q1_i
+ *   dinv[j] 3 per point:                     CHOLESKY  1/D of U_j+lambda I = L D L^T ; QR: 1
+ *   t[j]    3 per point:                     CHOLESKY  L^-1 g_p ;  QR: -Q1^T r  (= -q1)
+ *   tri[j]  upper 3x3 (6: 00 01 02 11 12 22) CHOLESKY  L^T (unit diag) ; QR: R1
+ * so that  S_ab = delta_ab (lambda I + sum A^T A) - sum_j Z_a diag(dinv) Z_b^T
+ *          rhs_a = g_c[a] - sum_{i in cam a} Z_i (dinv o t)
+ *          dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i])). */
+typedef struct {
+    S *Z, *dinv, *t, *tri;
+} FN(elim_t);
+
+/* CHOLESKY: block elimination of the point variables from (J^T J + lambda I) -- identical to LDL^T of
+ * the whole matrix (BacktrackLevMarqCholesky.h:274-282) with the point columns ordered first. */
+static void FN(elim_cholesky)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, S lambda,
+                              FN(elim_t) * e)
+{
+    for (int j = 0; j < M; j++) {
+        S U[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+        for (int i = pt_ptr[j]; i < pt_ptr[j + 1]; i++) {
+            const S *B = Jp + 6 * (size_t)i;
+            const S *r = fvec + 2 * (size_t)i;
+            U[0] += B[0] * B[0] + B[3] * B[3];
+            U[1] += B[0] * B[1] + B[3] * B[4];
+            U[2] += B[0] * B[2] + B[3] * B[5];
+            U[3] += B[1] * B[1] + B[4] * B[4];
+            U[4] += B[1] * B[2] + B[4] * B[5];
+            U[5] += B[2] * B[2] + B[5] * B[5];
+            for (int c = 0; c < 3; c++) gp[c] -= B[c] * r[0] + B[3 + c] * r[1];
+        }
+        const S d0 = U[0] + lambda;
+        const S l10 = U[1] / d0, l20 = U[2] / d0;
+        const S d1 = (U[3] + lambda) - l10 * l10 * d0;
+        const S l21 = (U[4] - l20 * l10 * d0) / d1;
+        const S d2 = (U[5] + lambda) - l20 * l20 * d0 - l21 * l21 * d1;
+        S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j, *tri = e->tri + 6 * (size_t)j;
+        dinv[0] = (S)1.0 / d0; dinv[1] = (S)1.0 / d1; dinv[2] = (S)1.0 / d2;
+        t[0] = gp[0]; t[1] = gp[1] - l10 * t[0]; t[2] = gp[2] - l20 * t[0] - l21 * t[1];
+        tri[0] = 1; tri[1] = l10; tri[2] = l20; tri[3] = 1; tri[4] = l21; tri[5] = 1;
+        for (int i = pt_ptr[j]; i < pt_ptr[j + 1]; i++) {
+            const S *A = Jc + 18 * (size_t)i, *B = Jp + 6 * (size_t)i;
+            S Bt[6]; /* B L^-T, 2x3 */
+            for (int r = 0; r < 2; r++) {
+                Bt[3 * r] = B[3 * r];
+                Bt[3 * r + 1] = B[3 * r + 1] - l10 * Bt[3 * r];
+                Bt[3 * r + 2] = B[3 * r + 2] - l20 * Bt[3 * r] - l21 * Bt[3 * r + 1];
+            }
+            S *Z = e->Z + 27 * (size_t)i;
+            for (int c = 0; c < 9; c++)
+                for (int m = 0; m < 3; m++) Z[3 * c + m] = A[c] * Bt[m] + A[9 + c] * Bt[3 + m];
+        }
+    }
+}
+
+/* QRCHOL / QRKIT left block: per point, unpivoted Householder QR of [(Jp)_j ; sqrt(lambda) I3]
+ * ((2k_j+3) x 3), the block BlockDiagonalSparseQR factors (BAFunctor.h:99-105, BAFunctor.cpp:64-68,
+ * BacktrackLevMarqQRChol.h:291-319).  Deviation (documented in DESIGN.md): the reference's dense block
+ * solver is ColPivHouseholderQR; with the sqrt(lambda) rows the block has full rank and the unpivoted
+ * factorisation solves the same least-squares problem.
+ * Q1 (thin Q, (2k+3) x 3) is formed explicitly; R12_i = Q1_i^T A_i ; q1 = Q1^T [r;0]. */
+static void FN(elim_qr)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, S lambda, FN(elim_t) * e,
+                        S *Q1obs /* K x 6 (2x3 per obs) or NULL */, S *Q1lam /* M x 9 or NULL */)
+{
+    const S sl = SQRT(lambda);
+    int kmax = 0;
+    for (int j = 0; j < M; j++)
+        if (pt_ptr[j + 1] - pt_ptr[j] > kmax) kmax = pt_ptr[j + 1] - pt_ptr[j];
+    const int mmax = 2 * kmax + 3;
+    S *Wk = (S *)malloc(sizeof(S) * 3 * (size_t)mmax); /* column-major m x 3 */
+    S *Q = (S *)malloc(sizeof(S) * 3 * (size_t)mmax);
+    for (int j = 0; j < M; j++) {
+        const int i0 = pt_ptr[j], k = pt_ptr[j + 1] - i0, m = 2 * k + 3;
+        for (int i = 0; i < k; i++) {
+            const S *B = Jp + 6 * (size_t)(i0 + i);
+            for (int c = 0; c < 3; c++) {
+                Wk[c * m + 2 * i] = B[c];
+                Wk[c * m + 2 * i + 1] = B[3 + c];
+            }
+        }
+        for (int c = 0; c < 3; c++)
+            for (int r = 0; r < 3; r++) Wk[c * m + 2 * k + r] = (r == c) ? sl : (S)0;
+        S tau[3];
+        for (int c = 0; c < 3; c++) {
+            S *col = Wk + c * m;
+            S xn = 0;
+            for (int r = c + 1; r < m; r++) xn += col[r] * col[r];
+            const S alpha = col[c];
+            S beta = SQRT(alpha * alpha + xn);
+            if (alpha > 0) beta = -beta;
+            tau[c] = (beta - alpha) / beta;
+            const S sc = (S)1.0 / (alpha - beta);
+            for (int r = c + 1; r < m; r++) col[r] *= sc;
+            col[c] = beta;
+            for (int c2 = c + 1; c2 < 3; c2++) {
+                S *cc = Wk + c2 * m;
+                S w = cc[c];
+                for (int r = c + 1; r < m; r++) w += col[r] * cc[r];
+                w *= tau[c];
+                cc[c] -= w;
+                for (int r = c + 1; r < m; r++) cc[r] -= col[r] * w;
+            }
+        }
+        /* thin Q = H0 H1 H2 [I3;0] */
+        for (int c = 0; c < 3; c++)
+            for (int r = 0; r < m; r++) Q[c * m + r] = (r == c) ? (S)1 : (S)0;
+        for (int h = 2; h >= 0; h--) {
+            const S *v = Wk + h * m;
+            for (int c = 0; c < 3; c++) {
+                S *qc = Q + c * m;
+                S w = qc[h];
+                for (int r = h + 1; r < m; r++) w += v[r] * qc[r];
+                w *= tau[h];
+                qc[h] -= w;
+                for (int r = h + 1; r < m; r++) qc[r] -= v[r] * w;
+            }
+        }
+        S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j, *tri = e->tri + 6 * (size_t)j;
+        dinv[0] = dinv[1] = dinv[2] = 1;
+        tri[0] = Wk[0]; tri[1] = Wk[m]; tri[2] = Wk[2 * m]; tri[3] = Wk[m + 1]; tri[4] = Wk[2 * m + 1];
+        tri[5] = Wk[2 * m + 2];
+        S q1[3] = {0, 0, 0};
+        for (int i = 0; i < k; i++) {
+            const S *A = Jc + 18 * (size_t)(i0 + i);
+            const S *r = fvec + 2 * (size_t)(i0 + i);
+            S Qi[6]; /* 2x3 row-major */
+            for (int c = 0; c < 3; c++) {
+                Qi[c] = Q[c * m + 2 * i];
+                Qi[3 + c] = Q[c * m + 2 * i + 1];
+                q1[c] += Qi[c] * r[0] + Qi[3 + c] * r[1];
+            }
+            if (Q1obs)
+                for (int c = 0; c < 6; c++) Q1obs[6 * (size_t)(i0 + i) + c] = Qi[c];
+            S *Z = e->Z + 27 * (size_t)(i0 + i);
+            for (int c = 0; c < 9; c++)
+                for (int mm = 0; mm < 3; mm++) Z[3 * c + mm] = A[c] * Qi[mm] + A[9 + c] * Qi[3 + mm];
+        }
+        if (Q1lam)
+            for (int c = 0; c < 3; c++)
+                for (int r = 0; r < 3; r++) Q1lam[9 * (size_t)j + 3 * r + c] = Q[c * m + 2 * k + r];
+        for (int c = 0; c < 3; c++) t[c] = -q1[c];
+    }
+    free(Wk);
+    free(Q);
+}
+
+/* Reduced camera system from the elimination workspace.
+ * Smat: D x D column-major (full symmetric), rhs: D, gc: D (camera part of g = -J^T r).
+ * QRCHOL: S = J2bot^T J2bot, rhs = -J2bot^T qtb2 (BacktrackLevMarqQRChol.h:334-341), evaluated as
+ * (A^T A + lambda I) - R12^T R12 and g_c + R12^T q1 -- algebraically identical because Q is orthogonal.
+ * CHOLESKY: the Schur complement of the point block of J^T J + lambda I. */
+static void FN(build_reduced)(int N, int K, const int *cam_idx, const int *pt_idx, const int *pt_ptr, int M,
+                              const S *Jc, const S *fvec, S lambda, const FN(elim_t) * e, S *Smat, S *rhs, S *gc)
+{
+    const int D = 9 * N;
+    memset(Smat, 0, sizeof(S) * (size_t)D * D);
+    for (int c = 0; c < D; c++) { rhs[c] = 0; gc[c] = 0; }
+    for (int i = 0; i < K; i++) {
+        const S *A = Jc + 18 * (size_t)i;
+        const S *r = fvec + 2 * (size_t)i;
+        const int a = cam_idx[i];
+        for (int c = 0; c < 9; c++) gc[9 * a + c] -= A[c] * r[0] + A[9 + c] * r[1];
+        for (int c = 0; c < 9; c++)
+            for (int c2 = 0; c2 < 9; c2++)
+                Smat[(size_t)(9 * a + c2) * D + 9 * a + c] += A[c] * A[c2] + A[9 + c] * A[9 + c2];
+    }
+    for (int j = 0; j < M; j++) {
+        const S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j;
+        const S td[3] = {dinv[0] * t[0], dinv[1] * t[1], dinv[2] * t[2]};
+        for (int ia = pt_ptr[j]; ia < pt_ptr[j + 1]; ia++) {
+            const S *Za = e->Z + 27 * (size_t)ia;
+            const int a = cam_idx[ia];
+            for (int c = 0; c < 9; c++) rhs[9 * a + c] -= Za[3 * c] * td[0] + Za[3 * c + 1] * td[1] + Za[3 * c + 2] * td[2];
+            for (int ib = pt_ptr[j]; ib < pt_ptr[j + 1]; ib++) {
+                const S *Zb = e->Z + 27 * (size_t)ib;
+                const int b = cam_idx[ib];
+                for (int c = 0; c < 9; c++) {
+                    const S z0 = Za[3 * c] * dinv[0], z1 = Za[3 * c + 1] * dinv[1], z2 = Za[3 * c + 2] * dinv[2];
+                    for (int c2 = 0; c2 < 9; c2++)
+                        Smat[(size_t)(9 * b + c2) * D + 9 * a + c] -= z0 * Zb[3 * c2] + z1 * Zb[3 * c2 + 1] + z2 * Zb[3 * c2 + 2];
+                }
+            }
+        }
+    }
+    (void)pt_idx;
+    for (int c = 0; c < D; c++) {
+        Smat[(size_t)c * D + c] += lambda;
+        rhs[c] += gc[c];
+    }
+}
+
+/* Back-substitution for the point steps (BacktrackLevMarqQRChol.h:343-360). dx = [3M points | 9N cameras]. */
+static void FN(backsub)(int M, const int *pt_ptr, const int *cam_idx, const FN(elim_t) * e, S *dx)
+{
+    const S *dxc = dx + 3 * (size_t)M;
+    for (int j = 0; j < M; j++) {
+        const S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j, *tri = e->tri + 6 * (size_t)j;
+        S u[3] = {t[0], t[1], t[2]};
+        for (int i = pt_ptr[j]; i < pt_ptr[j + 1]; i++) {
+            const S *Z = e->Z + 27 * (size_t)i;
+            const S *dc = dxc + 9 * (size_t)cam_idx[i];
+            for (int c = 0; c < 9; c++) {
+                u[0] -= Z[3 * c] * dc[c];
+                u[1] -= Z[3 * c + 1] * dc[c];
+                u[2] -= Z[3 * c + 2] * dc[c];
+            }
+        }
+        u[0] *= dinv[0]; u[1] *= dinv[1]; u[2] *= dinv[2];
+        const S x2 = u[2] / tri[5];
+        const S x1 = (u[1] - tri[4] * x2) / tri[3];
+        const S x0 = (u[0] - tri[1] * x1 - tri[2] * x2) / tri[0];
+        dx[3 * (size_t)j] = x0; dx[3 * (size_t)j + 1] = x1; dx[3 * (size_t)j + 2] = x2;
+    }
+}
+
+/* QRKIT right block: dense thin QR of J2bot (BAFunctor.h:101, README.md:14).
+ * J2bot = rows 3.. of every point block of Q^T [Jc;0], followed by sqrt(lambda) I_D; the rhs is qtb2.
+ * Built explicitly: for point j with thin Q1 (rows Q1_i per observation, Q1lam for the lambda rows) the
+ * projected rows are  P_j [A;0] with P_j = Q2^T; since only the span matters for the least-squares solve,
+ * the oracle uses the equivalent (I - Q1 Q1^T)[A;0] rows (same R up to an orthogonal row transform).
+ * Sized for small problems only (dense (2K+3M+D) x D). */
+static int FN(solve_reduced_qr)(int N, int M, int K, const int *cam_idx, const int *pt_ptr, const S *Jc, const S *fvec,
+                                S lambda, const S *Q1obs, const S *Q1lam, S *dxc)
+{
+    const int D = 9 * N;
+    const size_t m = 2 * (size_t)K + 3 * (size_t)M + D;
+    S *A2 = (S *)calloc(m * D, sizeof(S));
+    S *b2 = (S *)calloc(m, sizeof(S));
+    if (!A2 || !b2) { free(A2); free(b2); return -1; }
+    for (int j = 0; j < M; j++) {
+        const int i0 = pt_ptr[j], k = pt_ptr[j + 1] - i0;
+        const size_t row0 = 2 * (size_t)i0 + 3 * (size_t)j;
+        /* q1 = Q1^T [r;0] ; per camera column block: R12_a = Q1_a^T A_a */
+        S q1[3] = {0, 0, 0};
+        for (int i = 0; i < k; i++) {
+            const S *Qi = Q1obs + 6 * (size_t)(i0 + i);
+            const S *r = fvec + 2 * (size_t)(i0 + i);
+            for (int c = 0; c < 3; c++) q1[c] += Qi[c] * r[0] + Qi[3 + c] * r[1];
+        }
+        for (int ia = 0; ia < k; ia++) {
+            const S *A = Jc + 18 * (size_t)(i0 + ia);
+            const S *Qa = Q1obs + 6 * (size_t)(i0 + ia);
+            const int a = cam_idx[i0 + ia];
+            S R12[27]; /* 3x9 */
+            for (int mm = 0; mm < 3; mm++)
+                for (int c = 0; c < 9; c++) R12[9 * mm + c] = Qa[mm] * A[c] + Qa[3 + mm] * A[9 + c];
+            for (int c = 0; c < 9; c++) {
+                S *col = A2 + (size_t)(9 * a + c) * m + row0;
+                for (int ib = 0; ib < k; ib++) {
+                    const S *Qb = Q1obs + 6 * (size_t)(i0 + ib);
+                    for (int rr = 0; rr < 2; rr++) {
+                        S v = (ib == ia) ? A[9 * rr + c] : (S)0;
+                        v -= Qb[3 * rr] * R12[c] + Qb[3 * rr + 1] * R12[9 + c] + Qb[3 * rr + 2] * R12[18 + c];
+                        col[2 * ib + rr] += v;
+                    }
+                }
+                const S *Ql = Q1lam + 9 * (size_t)j;
+                for (int rr = 0; rr < 3; rr++)
+                    col[2 * k + rr] -= Ql[3 * rr] * R12[c] + Ql[3 * rr + 1] * R12[9 + c] + Ql[3 * rr + 2] * R12[18 + c];
+            }
+        }
+        for (int ib = 0; ib < k; ib++) {
+            const S *Qb = Q1obs + 6 * (size_t)(i0 + ib);
+            const S *r = fvec + 2 * (size_t)(i0 + ib);
+            for (int rr = 0; rr < 2; rr++)
+                b2[row0 + 2 * ib + rr] = r[rr] - (Qb[3 * rr] * q1[0] + Qb[3 * rr + 1] * q1[1] + Qb[3 * rr + 2] * q1[2]);
+        }
+        const S *Ql = Q1lam + 9 * (size_t)j;
+        for (int rr = 0; rr < 3; rr++)
+            b2[row0 + 2 * k + rr] = -(Ql[3 * rr] * q1[0] + Ql[3 * rr + 1] * q1[1] + Ql[3 * rr + 2] * q1[2]);
+    }
+    const S sl = SQRT(lambda);
+    for (int c = 0; c < D; c++) A2[(size_t)c * m + 2 * (size_t)K + 3 * (size_t)M + c] = sl;
+    /* min || J2bot dx_c + qtb2 || */
+    for (size_t r = 0; r < m; r++) b2[r] = -b2[r];
+    FN(dense_qr_solve)((int)m, D, A2, b2, dxc);
+    free(A2);
+    free(b2);
+    return 0;
+}
+
+/* g = -J^T r (the reference's JtRes, BacktrackLevMarqQRChol.h:267 / ...Cholesky.h:250) and
+ * max diag(J^T J) (squared column norms, ...QRChol.h:270-280; JtJ.diagonal().maxCoeff(), ...Cholesky.h:263-265). */
+static void FN(grad_diag)(int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp,
+                          const S *fvec, S *gout, S *diagmax)
+{
+    const size_t np = 3 * (size_t)M + 9 * (size_t)N;
+    S *dg = (S *)calloc(np, sizeof(S));
+    if (gout)
+        for (size_t c = 0; c < np; c++) gout[c] = 0;
+    for (int i = 0; i < K; i++) {
+        const S *A = Jc + 18 * (size_t)i, *B = Jp + 6 * (size_t)i, *r = fvec + 2 * (size_t)i;
+        for (int c = 0; c < 3; c++) {
+            if (gout) gout[3 * (size_t)pt_idx[i] + c] -= B[c] * r[0] + B[3 + c] * r[1];
+            dg[3 * (size_t)pt_idx[i] + c] += B[c] * B[c] + B[3 + c] * B[3 + c];
+        }
+        for (int c = 0; c < 9; c++) {
+            if (gout) gout[3 * (size_t)M + 9 * (size_t)cam_idx[i] + c] -= A[c] * r[0] + A[9 + c] * r[1];
+            dg[3 * (size_t)M + 9 * (size_t)cam_idx[i] + c] += A[c] * A[c] + A[9 + c] * A[9 + c];
+        }
+    }
+    S dm = 0;
+    for (size_t c = 0; c < np; c++)
+        if (dg[c] > dm) dm = dg[c];
+    free(dg);
+    if (diagmax) *diagmax = dm;
+}
+
+/* One LM trial's linear solve: dx (3M+9N) from J, r, lambda.  kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY.
+ * Optional outputs (may be NULL): Sout D*D col-major, rhsout D, gout 3M+9N (= -J^T r, the reference's JtRes,
+ * BacktrackLevMarqQRChol.h:267), diagmax = max diag(J^T J) (:270-280). */
+int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp,
+                 const S *fvec, S lambda, S *dx, S *Sout, S *rhsout, S *gout, S *diagmax)
+{
+    const int D = 9 * N;
+    int *pt_ptr = (int *)malloc(sizeof(int) * ((size_t)M + 1));
+    /* observations must be sorted by point (BAL files are; BacktrackLevMarqQRChol.h:291-309 relies on it) */
+    {
+        int p = 0;
+        pt_ptr[0] = 0;
+        for (int i = 0; i < K; i++) {
+            if (pt_idx[i] < p) { free(pt_ptr); return -2; }
+            while (p < pt_idx[i]) pt_ptr[++p] = i;
+        }
+        while (p < M) pt_ptr[++p] = K;
+    }
+    FN(elim_t) e;
+    e.Z = (S *)malloc(sizeof(S) * 27 * (size_t)K);
+    e.dinv = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    e.t = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    e.tri = (S *)malloc(sizeof(S) * 6 * (size_t)M);
+    S *Smat = (S *)malloc(sizeof(S) * (size_t)D * D);
+    S *rhs = (S *)malloc(sizeof(S) * (size_t)D);
+    S *gc = (S *)malloc(sizeof(S) * (size_t)D);
+    S *Q1obs = NULL, *Q1lam = NULL;
+    int rc = 0;
+    if (kind == 2) {
+        FN(elim_cholesky)(M, pt_ptr, Jc, Jp, fvec, lambda, &e);
+    } else {
+        if (kind == 0) {
+            Q1obs = (S *)malloc(sizeof(S) * 6 * (size_t)K);
+            Q1lam = (S *)malloc(sizeof(S) * 9 * (size_t)M);
+        }
+        FN(elim_qr)(M, pt_ptr, Jc, Jp, fvec, lambda, &e, Q1obs, Q1lam);
+    }
+    FN(build_reduced)(N, K, cam_idx, pt_idx, pt_ptr, M, Jc, fvec, lambda, &e, Smat, rhs, gc);
+    if (Sout) memcpy(Sout, Smat, sizeof(S) * (size_t)D * D);
+    if (rhsout) memcpy(rhsout, rhs, sizeof(S) * (size_t)D);
+    S *dxc = dx + 3 * (size_t)M;
+    if (kind == 0) {
+        rc = FN(solve_reduced_qr)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, Q1obs, Q1lam, dxc);
+    } else {
+        FN(dense_ldlt)(D, Smat);
+        FN(dense_ldlt_solve)(D, Smat, rhs);
+        for (int c = 0; c < D; c++) dxc[c] = rhs[c];
+    }
+    FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
+    if (gout || diagmax) FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, gout, diagmax);
+    free(Q1obs); free(Q1lam);
+    free(e.Z); free(e.dinv); free(e.t); free(e.tri);
+    free(Smat); free(rhs); free(gc); free(pt_ptr);
+    return rc;
+}
+
+/* ---- LM outer loop -------------------------------------------------------------------- */
+
+/* BacktrackLevMarqQRCHol::minimize (BacktrackLevMarqQRChol.h:204-436) and
+ * BacktrackLevMarqCholesky::minimize (BacktrackLevMarqCholesky.h:190-361): same skeleton, different
+ * inner solve.  QRKIT's loop (Eigen::BacktrackLevMarq) is not vendored; it reuses this skeleton.
+ * lm = {lambda_min, lambda_max, increase_base, tol_fun}; max_iter / max_fun_ev as LMParams.
+ * trace: max_trials rows of 8 doubles {iter, accepted, f, rho, lambda_printed, lambda_used, e_test, |dx|}
+ * (one row per printed table line, BacktrackLevMarqQRChol.h:383,397).  Stops early (status Running = -1)
+ * after max_trials rows.  cam15/pts are updated in place with the reference's quirk that the flat-line
+ * exit happens BEFORE x = xTest (:419-428).  Returns the Status integer (:39-46). */
+int FN(ora_minimize)(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *meas, S tau,
+                     S *cam15, S *pts, const double *lm, int max_iter, int max_fun_ev, int max_trials, double *trace,
+                     int *ntrials_out)
+{
+    const S lam_min = (S)lm[0], lam_max = (S)lm[1], inc_base = (S)lm[2], tol_fun = (S)lm[3];
+    const size_t np = 3 * (size_t)M + 9 * (size_t)N;
+    S *fvec = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    S *Jc = (S *)malloc(sizeof(S) * 18 * (size_t)K);
+    S *Jp = (S *)malloc(sizeof(S) * 6 * (size_t)K);
+    S *dx = (S *)malloc(sizeof(S) * np);
+    S *g = (S *)malloc(sizeof(S) * np);
+    S *camT = (S *)malloc(sizeof(S) * 15 * (size_t)N);
+    S *ptsT = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    S lambda = (S)1e-3, lambda_inc = inc_base;
+    S hist[2] = {0, 0};
+    int fun_evals = 0, iter = 0, status = -1, ntr = 0, stop = 0;
+    S energy = 0;
+    while (1) {
+        iter++;
+        if (iter > max_iter) { status = 3; break; }
+        if (fun_evals > max_fun_ev) { status = 2; break; }
+        energy = FN(ora_residuals)(N, M, K, cam15, pts, cam_idx, pt_idx, meas, tau, fvec);
+        fun_evals++;
+        FN(ora_jacobian)(N, M, K, cam15, pts, cam_idx, pt_idx, meas, tau, Jc, Jp);
+        {
+            S dmax = 0;
+            FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, g, &dmax);
+            /* lambda0 = 1e-12 * max diag(J^T J) (BacktrackLevMarqQRChol.h:278-280; ...Cholesky.h:263-265) */
+            if (iter == 1) lambda = (S)(1e-12 * (double)dmax);
+        }
+        while (1) {
+            if (ntr >= max_trials) { stop = 1; status = -1; break; }
+            const int rc = FN(ora_step)(kind, N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, lambda, dx, NULL, NULL, NULL, NULL);
+            if (rc) { status = -3; stop = 1; break; }
+            FN(ora_retract)(N, M, cam15, pts, dx, camT, ptsT);
+            const S e_test = FN(ora_residuals)(N, M, K, camT, ptsT, cam_idx, pt_idx, meas, tau, NULL);
+            fun_evals++;
+            S dxn = 0;
+            for (size_t c = 0; c < np; c++) dxn += dx[c] * dx[c];
+            double *row = trace ? trace + 8 * (size_t)ntr : NULL;
+            if (e_test < energy) {
+                S rho_scale = 0;
+                for (size_t c = 0; c < np; c++) rho_scale += dx[c] * (lambda * dx[c] + g[c]);
+                const S rho = (energy - e_test) / rho_scale;
+                const S lam_used = lambda;
+                const S tm = (S)2.0 * rho - (S)1.0;
+                S mul = (S)1.0 - tm * tm * tm;
+                if (mul < (S)1.0 / (S)3.0) mul = (S)1.0 / (S)3.0;
+                lambda *= mul;
+                if (lambda < lam_min) lambda = lam_min;
+                if (row) {
+                    row[0] = iter; row[1] = 1; row[2] = (double)energy; row[3] = (double)rho; row[4] = (double)lambda;
+                    row[5] = (double)lam_used; row[6] = (double)e_test; row[7] = sqrt((double)dxn);
+                }
+                ntr++;
+                lambda_inc = inc_base;
+                energy = e_test;
+                hist[iter % 2] = energy;
+                break;
+            } else {
+                if (row) {
+                    row[0] = iter; row[1] = 0; row[2] = (double)energy; row[3] = 0; row[4] = (double)lambda;
+                    row[5] = (double)lambda; row[6] = (double)e_test; row[7] = sqrt((double)dxn);
+                }
+                ntr++;
+                if (lambda > lam_max) { status = 1; stop = 1; break; }
+                lambda *= lambda_inc;
+                lambda_inc = POW(lambda_inc, (S)1.5);
+            }
+        }
+        if (stop) break;
+        if (iter > 2) {
+            const S maxf = hist[0] > hist[1] ? hist[0] : hist[1];
+            if (FABS(energy - maxf) < tol_fun * energy) { status = 0; break; }
+        }
+        memcpy(cam15, camT, sizeof(S) * 15 * (size_t)N);
+        memcpy(pts, ptsT, sizeof(S) * 3 * (size_t)M);
+    }
+    if (ntrials_out) *ntrials_out = ntr;
+    free(fvec); free(Jc); free(Jp); free(dx); free(g); free(camT); free(ptsT);
+    return status;
+}
+
+#undef EPS_PSI
