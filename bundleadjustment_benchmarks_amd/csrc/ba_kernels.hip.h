@@ -1,0 +1,638 @@
+// ba_kernels.hip.h -- gfx950 kernels of the bundle-adjustment LM trial, templated on Scalar (double / float,
+// src/BATypeUtils.h:6-7).  64-wide wavefronts; all cross-lane sums use a fixed order, so results are run-to-run
+// reproducible.  HBM layout:
+//   cam   T[15][N]   SoA  R row-major (9), T (3), f = K(0,0), k1, k2       (state, x and xTest copies)
+//   pts   T[3][Ml]   SoA
+//   meas  T[2][Kl], r T[2][Kl], Jc T[18][Kl] (2x9 row-major per obs), Jp T[6][Kl]   SoA over observations
+//   rec   T[Kl][36]  AoS  per observation: Z (9x3 row-major) then zt = Z (dinv o t)  -- gathered by the pair kernel
+//   U0 T[6][Ml], gp T[3][Ml], dinv T[3][Ml], tvec T[3][Ml], tri T[6][Ml]            per point
+//   S     T[Dp][Dp]  column-major, lower triangle + augmented rows D (rhs), D+1 (g_c), D+2 (scalars)
+#ifndef BA_KERNELS_HIP_H
+#define BA_KERNELS_HIP_H
+
+#include <hip/hip_runtime.h>
+
+#define BA_REC 36
+#define BA_SLAB 96
+#define BA_EPS_PSI 1e-15 /* src/Optimization/BAFunctor.h:159 */
+
+__device__ __forceinline__ double tsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float tsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double tsin(double x) { return sin(x); }
+__device__ __forceinline__ float tsin(float x) { return sinf(x); }
+__device__ __forceinline__ double tcos(double x) { return cos(x); }
+__device__ __forceinline__ float tcos(float x) { return cosf(x); }
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+
+// ---- block reductions (fixed order: shuffle tree inside a wave, then waves in index order) -----------------
+template <typename T, bool MAX> __device__ __forceinline__ T wave_reduce(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_down(v, off, 64);
+        v = MAX ? tmax(v, o) : v + o;
+    }
+    return v;
+}
+
+template <typename T, bool MAX> __device__ __forceinline__ T block_reduce(T v, T *lds /* >= blockDim/64 */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_reduce<T, MAX>(v);
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    T a = lds[0];
+    for (int k = 1; k < nw; k++) a = MAX ? tmax(a, lds[k]) : a + lds[k];
+    return a;
+}
+
+// ---- K1/K2: residual (+ Jacobian) per observation ------------------------------------------------------------
+// BAFunctor::E_pos (src/Optimization/BAFunctor.h:160-178) and dE_pos (:181-297) with poseDerivatives (:126-142),
+// DistortionFunction (src/DistortionFunction.cpp:14-51), transformPointIntoCameraSpace (src/CameraMatrix.cpp:259-261).
+// One thread per observation; camera / point parameters are gathered (observations are point-sorted, so a wave's
+// point reads are near-contiguous and the 15N camera scalars stay in L2), everything else is a coalesced SoA stream.
+template <typename T, bool JAC>
+__global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__restrict__ cam, const T *__restrict__ pts,
+                                              const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                              const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
+                                              T *__restrict__ Jp, T *__restrict__ partial)
+{
+    __shared__ T red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    T e2 = 0;
+    if (i < K) {
+        const int ci = obs_cam[i], pj = obs_pt[i];
+        T c[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) c[k] = cam[(size_t)k * N + ci];
+        const T X0 = pts[pj], X1 = pts[(size_t)Ml + pj], X2 = pts[2 * (size_t)Ml + pj];
+        const T RX0 = c[0] * X0 + c[1] * X1 + c[2] * X2;
+        const T RX1 = c[3] * X0 + c[4] * X1 + c[5] * X2;
+        const T RX2 = c[6] * X0 + c[7] * X1 + c[8] * X2;
+        const T XX0 = RX0 + c[9], XX1 = RX1 + c[10], XX2 = RX2 + c[11];
+        const T xu0 = XX0 / XX2, xu1 = XX1 / XX2;
+        const T r2u = xu0 * xu0 + xu1 * xu1, r4u = r2u * r2u;
+        const T f = c[12], k1 = c[13], k2 = c[14];
+        const T kr = 1 + k1 * r2u + k2 * r4u;
+        const T xd0 = kr * xu0, xd1 = kr * xu1;
+        const T r0 = f * xd0 - meas[i], r1 = f * xd1 - meas[(size_t)K + i];
+        const T r2 = r0 * r0 + r1 * r1;
+        // psi (BAFunctor.h:147)
+        const T psi = (r2 < tau2) ? r2 * ((T)2.0 - r2 / tau2) / (T)4.0 : tau2 / (T)4.0;
+        const T sqrt_psi = tsqrt(psi);
+        const T nr = tsqrt(r2);
+        const T rnorm_r = (T)1.0 / tmax((T)BA_EPS_PSI, nr);
+        const T e0 = r0 * sqrt_psi * rnorm_r, e1 = r1 * sqrt_psi * rnorm_r;
+        e2 = e0 * e0 + e1 * e1;
+        if (JAC) {
+            r[i] = e0;
+            r[(size_t)K + i] = e1;
+            // -[XX - T]x  (poseDerivatives, BAFunctor.h:131-133; XX - T is formed as the reference forms it)
+            const T v0 = XX0 - c[9], v1 = XX1 - c[10], v2 = XX2 - c[11];
+            const T mJ[9] = {0, v2, -v1, -v2, 0, v0, v1, -v0, 0};
+            const T a00 = (T)1.0 / XX2, a02 = -XX0 / (XX2 * XX2), a12 = -XX1 / (XX2 * XX2);
+            const T dkr = 2 * k1 + 4 * k2 * r2u;
+            const T d00 = kr + xu0 * xu0 * dkr, d01 = xu0 * xu1 * dkr, d11 = kr + xu1 * xu1 * dkr;
+            const T p00 = f * d00, p01 = f * d01, p11 = f * d11;
+            T dpX[6];
+            dpX[0] = p00 * a00; dpX[1] = p01 * a00; dpX[2] = p00 * a02 + p01 * a12;
+            dpX[3] = p01 * a00; dpX[4] = p11 * a00; dpX[5] = p01 * a02 + p11 * a12;
+            // outer derivative of the robustified residual (BAFunctor.h:227-242)
+            const T tw = (T)1.0 - r2 / tau2;
+            const T W = tw > (T)0 ? tw : (T)0;
+            const T rsqrt_psi = (T)1.0 / tmax((T)BA_EPS_PSI, sqrt_psi);
+            const T rcp_r2 = (T)1.0 / tmax((T)BA_EPS_PSI, r2);
+            const T rr00 = r0 * r0 * rnorm_r, rr01 = r0 * r1 * rnorm_r, rr11 = r1 * r1 * rnorm_r;
+            const T c1 = W / (T)2.0 * rsqrt_psi, c2 = sqrt_psi * rcp_r2;
+            const T o00 = c1 * rr00 + c2 * (nr - rr00);
+            const T o01 = c1 * rr01 + c2 * ((T)0 - rr01);
+            const T o11 = c1 * rr11 + c2 * (nr - rr11);
+            T Jb[24];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const T *d = dpX + 3 * rr;
+                T *o = Jb + 12 * rr;
+                o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
+#pragma unroll
+                for (int q = 0; q < 3; q++) o[3 + q] = d[0] * mJ[q] + d[1] * mJ[3 + q] + d[2] * mJ[6 + q];
+#pragma unroll
+                for (int q = 0; q < 3; q++) o[9 + q] = d[0] * c[q] + d[1] * c[3 + q] + d[2] * c[6 + q];
+            }
+            Jb[6] = xd0; Jb[18] = xd1;
+            Jb[7] = f * (xu0 * r2u); Jb[8] = f * (xu0 * r4u);
+            Jb[19] = f * (xu1 * r2u); Jb[20] = f * (xu1 * r4u);
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                const T t0 = o00 * Jb[q] + o01 * Jb[12 + q];
+                const T t1 = o01 * Jb[q] + o11 * Jb[12 + q];
+                if (q < 9) {
+                    Jc[(size_t)q * K + i] = t0;
+                    Jc[(size_t)(9 + q) * K + i] = t1;
+                } else {
+                    Jp[(size_t)(q - 9) * K + i] = t0;
+                    Jp[(size_t)(q - 6) * K + i] = t1;
+                }
+            }
+        }
+    }
+    e2 = block_reduce<T, false>(e2, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = e2;
+}
+
+// Utils::showErrorStatistics / showObjective (src/Utils.h:10-68): 4 partial sums per block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_stats(int K, int N, int Ml, const T *__restrict__ cam, const T *__restrict__ pts,
+                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                               const T *__restrict__ meas, T tau, T *__restrict__ partial /* [4][grid] */)
+{
+    __shared__ T red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    T v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (i < K) {
+        const int ci = obs_cam[i], pj = obs_pt[i];
+        T c[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) c[k] = cam[(size_t)k * N + ci];
+        const T X0 = pts[pj], X1 = pts[(size_t)Ml + pj], X2 = pts[2 * (size_t)Ml + pj];
+        const T XX0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+        const T XX1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+        const T XX2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+        const T xu0 = XX0 / XX2, xu1 = XX1 / XX2;
+        const T r2u = xu0 * xu0 + xu1 * xu1;
+        const T kr = 1 + c[13] * r2u + c[14] * r2u * r2u;
+        const T d0 = c[12] * (kr * xu0) - meas[i], d1 = c[12] * (kr * xu1) - meas[(size_t)K + i];
+        const T err = tsqrt(d0 * d0 + d1 * d1);
+        const T tau2 = tau * tau, tau4 = tau2 * tau2;
+        v0 = err;
+        if (err <= tau) { v1 = err; v2 = 1; }
+        const T q2 = err, q4 = q2 * q2; // sic: the norm, not its square, goes into Utils::psi (Utils.h:61-62)
+        v3 = (q2 < tau2) ? q2 * ((T)3.0 - (T)3.0 * q2 / tau2 + q4 / tau4) / (T)6.0 : tau2 / (T)6.0;
+    }
+    v0 = block_reduce<T, false>(v0, red);
+    v1 = block_reduce<T, false>(v1, red);
+    v2 = block_reduce<T, false>(v2, red);
+    v3 = block_reduce<T, false>(v3, red);
+    if (threadIdx.x == 0) {
+        const size_t g = gridDim.x;
+        partial[blockIdx.x] = v0; partial[g + blockIdx.x] = v1; partial[2 * g + blockIdx.x] = v2; partial[3 * g + blockIdx.x] = v3;
+    }
+}
+
+// ---- second stage of every scalar reduction: up to 8 (array, count, op) jobs, one block each ----------------
+struct ba_red_job { const void *src; int n; int op; int dst; }; // op 0 sum, 1 max
+struct ba_red_jobs { ba_red_job j[8]; };
+
+template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal)
+{
+    __shared__ T red[4];
+    const ba_red_job jb = jobs.j[blockIdx.x];
+    const T *src = (const T *)jb.src;
+    T a = 0;
+    if (jb.op == 0) {
+        for (int k = threadIdx.x; k < jb.n; k += 256) a += src[k];
+        a = block_reduce<T, false>(a, red);
+    } else {
+        for (int k = threadIdx.x; k < jb.n; k += 256) a = tmax(a, src[k]);
+        a = block_reduce<T, true>(a, red);
+    }
+    if (threadIdx.x == 0) scal[jb.dst] = a;
+}
+
+// ---- K3 (point part): U0_j = sum B^T B, g_p = -sum B^T r per point, once per outer iteration ------------------
+// JtRes and the squared column norms of the point columns (src/Eigen_ext/BacktrackLevMarqQRChol.h:267-274).
+template <typename T>
+__global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
+                                                    const T *__restrict__ r, T *__restrict__ U0, T *__restrict__ gp,
+                                                    T *__restrict__ partial_dmax)
+{
+    __shared__ T red[4];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    T dm = 0;
+    if (j < Ml) {
+        T U[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        const int e = pt_ptr[j + 1];
+        for (int i = pt_ptr[j]; i < e; i++) {
+            T B[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) B[q] = Jp[(size_t)q * K + i];
+            const T r0 = r[i], r1 = r[(size_t)K + i];
+            U[0] += B[0] * B[0] + B[3] * B[3];
+            U[1] += B[0] * B[1] + B[3] * B[4];
+            U[2] += B[0] * B[2] + B[3] * B[5];
+            U[3] += B[1] * B[1] + B[4] * B[4];
+            U[4] += B[1] * B[2] + B[4] * B[5];
+            U[5] += B[2] * B[2] + B[5] * B[5];
+#pragma unroll
+            for (int q = 0; q < 3; q++) g[q] -= B[q] * r0 + B[3 + q] * r1;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) U0[(size_t)q * Ml + j] = U[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) gp[(size_t)q * Ml + j] = g[q];
+        dm = tmax(U[0], tmax(U[3], U[5]));
+    }
+    dm = block_reduce<T, true>(dm, red);
+    if (threadIdx.x == 0) partial_dmax[blockIdx.x] = dm;
+}
+
+// ---- K3 (camera part): V_aa = sum A^T A (9x9) and g_c = -sum A^T r per camera, once per outer iteration -------
+// One 32-lane group per chunk of <= chunk_len observations of one camera; lane (c, q) owns V[c][3q..3q+2].
+template <typename T>
+__global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
+                                                  const int *__restrict__ cam_obs, const T *__restrict__ Jc,
+                                                  const T *__restrict__ r, T *__restrict__ dslab)
+{
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
+    if (g >= ndchunks) return;
+    const int c = sub / 3, q = sub - 3 * c;
+    const bool act = sub < 27;
+    T acc[3] = {0, 0, 0}, gacc = 0;
+    const int e1 = dchunk_ptr[g + 1];
+    for (int e = dchunk_ptr[g]; e < e1; e++) {
+        const int i = cam_obs[e];
+        if (act) {
+            const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+                acc[jj] += a0 * Jc[(size_t)(3 * q + jj) * K + i] + a1 * Jc[(size_t)(9 + 3 * q + jj) * K + i];
+            if (sub < 9) gacc -= Jc[(size_t)sub * K + i] * r[i] + Jc[(size_t)(9 + sub) * K + i] * r[(size_t)K + i];
+        }
+    }
+    T *o = dslab + (size_t)g * BA_SLAB;
+    if (act) {
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) o[9 * c + 3 * q + jj] = acc[jj];
+        if (sub < 9) o[81 + sub] = gacc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(192) void k_cam_gram_reduce(int N, const int *__restrict__ cam_dchunk_ptr,
+                                                         const T *__restrict__ dslab, T *__restrict__ V /* [N][81] */,
+                                                         T *__restrict__ gc /* [9N] */)
+{
+    const int idx = blockIdx.x * 192 + threadIdx.x;
+    const int a = idx / BA_SLAB, e = idx - a * BA_SLAB;
+    if (a >= N || e >= 90) return;
+    T s = 0;
+    const int c1 = cam_dchunk_ptr[a + 1];
+    for (int c = cam_dchunk_ptr[a]; c < c1; c++) s += dslab[(size_t)c * BA_SLAB + e];
+    if (e < 81) V[(size_t)a * 81 + e] = s;
+    else gc[9 * a + e - 81] = s;
+}
+
+// diagonal of J_c^T J_c (squared column norms of the camera columns, BacktrackLevMarqQRChol.h:270-274)
+template <typename T> __global__ __launch_bounds__(256) void k_vdiag(int N, const T *__restrict__ V, T *__restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < 9 * N) out[c] = V[(size_t)(c / 9) * 81 + 10 * (c % 9)];
+}
+
+// ---- K4 (CHOLESKY): eliminate the 3x3 point block of J^T J + lambda I ----------------------------------------
+// LDL^T of the whole matrix with the point columns first (src/Eigen_ext/BacktrackLevMarqCholesky.h:274-282):
+// U_j + lambda I = L D L^T;  Z_i = A_i^T (B_i L^-T) = W_i L^-T;  t = L^-1 g_p.  One thread per observation (each
+// recomputes its point's 3x3 LDL^T: 20 flops, cheaper than a second launch); the first observation of a point also
+// writes the per-point factors.
+template <typename T>
+__global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
+                                                   const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ U0,
+                                                   const T *__restrict__ gp, T lambda, T *__restrict__ rec,
+                                                   T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const int j = obs_pt[i];
+    const T u0 = U0[j], u1 = U0[(size_t)Ml + j], u2 = U0[2 * (size_t)Ml + j], u3 = U0[3 * (size_t)Ml + j],
+            u4 = U0[4 * (size_t)Ml + j], u5 = U0[5 * (size_t)Ml + j];
+    const T d0 = u0 + lambda;
+    const T l10 = u1 / d0, l20 = u2 / d0;
+    const T d1 = (u3 + lambda) - l10 * l10 * d0;
+    const T l21 = (u4 - l20 * l10 * d0) / d1;
+    const T d2 = (u5 + lambda) - l20 * l20 * d0 - l21 * l21 * d1;
+    const T i0 = (T)1.0 / d0, i1 = (T)1.0 / d1, i2 = (T)1.0 / d2;
+    const T g0 = gp[j], g1 = gp[(size_t)Ml + j], g2 = gp[2 * (size_t)Ml + j];
+    const T t0 = g0, t1 = g1 - l10 * t0, t2 = g2 - l20 * t0 - l21 * t1;
+    if (i == pt_ptr[j]) {
+        dinv[j] = i0; dinv[(size_t)Ml + j] = i1; dinv[2 * (size_t)Ml + j] = i2;
+        tvec[j] = t0; tvec[(size_t)Ml + j] = t1; tvec[2 * (size_t)Ml + j] = t2;
+        tri[j] = 1; tri[(size_t)Ml + j] = l10; tri[2 * (size_t)Ml + j] = l20;
+        tri[3 * (size_t)Ml + j] = 1; tri[4 * (size_t)Ml + j] = l21; tri[5 * (size_t)Ml + j] = 1;
+    }
+    T Bt[6];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const T b0 = Jp[(size_t)(3 * rr) * K + i], b1 = Jp[(size_t)(3 * rr + 1) * K + i], b2 = Jp[(size_t)(3 * rr + 2) * K + i];
+        Bt[3 * rr] = b0;
+        Bt[3 * rr + 1] = b1 - l10 * Bt[3 * rr];
+        Bt[3 * rr + 2] = b2 - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
+    }
+    const T td0 = i0 * t0, td1 = i1 * t1, td2 = i2 * t2;
+    T *o = rec + (size_t)i * BA_REC;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
+        const T z0 = a0 * Bt[0] + a1 * Bt[3], z1 = a0 * Bt[1] + a1 * Bt[4], z2 = a0 * Bt[2] + a1 * Bt[5];
+        o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
+        o[27 + c] = z0 * td0 + z1 * td1 + z2 * td2;
+    }
+}
+
+// ---- K4 (QRCHOL / QRKIT left block): Householder QR of [sqrt(lambda) I3 ; (Jp)_j] per point ------------------
+// The block BlockDiagonalSparseQR factors (src/Optimization/BAFunctor.h:99-105, BAFunctor.cpp:64-68,
+// src/Eigen_ext/BacktrackLevMarqQRChol.h:291-319), rows permuted so that the three sqrt(lambda) rows come first
+// (R and Q1 are unique up to row / column signs, which cancel in S, the reduced rhs and dx), unpivoted.
+// One thread per point; the (2 k_j) x 3 observation rows live in the scratch Qw[6][K]: first B, then the
+// Householder vectors, finally the thin Q1 rows of the observations.
+template <typename T>
+__global__ __launch_bounds__(256) void k_elim_qr_point(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
+                                                       const T *__restrict__ r, T lambda, T *__restrict__ Qw /* [6][K] */,
+                                                       T *__restrict__ Vw /* [6][K] */, T *__restrict__ dinv,
+                                                       T *__restrict__ tvec, T *__restrict__ tri, T *__restrict__ Qlam /* [9][Ml] or null */)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Ml) return;
+    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    const T sl = tsqrt(lambda);
+    for (int i = b; i < e; i++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) Vw[(size_t)q * K + i] = Jp[(size_t)q * K + i];
+    // column c of observation row (i, rr) is Vw[3 rr + c][i]
+    T R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tau[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        T xn = 0;
+        for (int i = b; i < e; i++) {
+            const T x0 = Vw[(size_t)c * K + i], x1 = Vw[(size_t)(3 + c) * K + i];
+            xn += x0 * x0 + x1 * x1;
+        }
+        const T alpha = sl;                        // the lambda row c is untouched by the earlier reflectors
+        const T beta = -tsqrt(alpha * alpha + xn); // alpha > 0
+        tau[c] = (beta - alpha) / beta;
+        const T sc = (T)1.0 / (alpha - beta);
+        for (int i = b; i < e; i++) {
+            Vw[(size_t)c * K + i] *= sc;
+            Vw[(size_t)(3 + c) * K + i] *= sc;
+        }
+        R[c][c] = beta;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 3; c2++) {
+            T w = 0; // the pivot-row entry of column c2 is still zero
+            for (int i = b; i < e; i++)
+                w += Vw[(size_t)c * K + i] * Vw[(size_t)c2 * K + i] + Vw[(size_t)(3 + c) * K + i] * Vw[(size_t)(3 + c2) * K + i];
+            w *= tau[c];
+            R[c][c2] = -w;
+            for (int i = b; i < e; i++) {
+                Vw[(size_t)c2 * K + i] -= Vw[(size_t)c * K + i] * w;
+                Vw[(size_t)(3 + c2) * K + i] -= Vw[(size_t)(3 + c) * K + i] * w;
+            }
+        }
+    }
+    // thin Q1 = H0 H1 H2 [I3; 0]
+    T Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; // lambda rows of Q1
+    for (int i = b; i < e; i++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) Qw[(size_t)q * K + i] = 0;
+#pragma unroll
+    for (int h = 2; h >= 0; h--) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            T w = Ql[h][c];
+            for (int i = b; i < e; i++)
+                w += Vw[(size_t)h * K + i] * Qw[(size_t)c * K + i] + Vw[(size_t)(3 + h) * K + i] * Qw[(size_t)(3 + c) * K + i];
+            w *= tau[h];
+            Ql[h][c] -= w;
+            for (int i = b; i < e; i++) {
+                Qw[(size_t)c * K + i] -= Vw[(size_t)h * K + i] * w;
+                Qw[(size_t)(3 + c) * K + i] -= Vw[(size_t)(3 + h) * K + i] * w;
+            }
+        }
+    }
+    // t = -Q1^T [0; r]
+    T q1[3] = {0, 0, 0};
+    for (int i = b; i < e; i++) {
+        const T r0 = r[i], r1 = r[(size_t)K + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) q1[c] += Qw[(size_t)c * K + i] * r0 + Qw[(size_t)(3 + c) * K + i] * r1;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        dinv[(size_t)c * Ml + j] = 1;
+        tvec[(size_t)c * Ml + j] = -q1[c];
+    }
+    tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
+    tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
+    if (Qlam)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Qlam[(size_t)(3 * rr + c) * Ml + j] = Ql[rr][c];
+}
+
+// R12_i^T = A_i^T Q1_i (9x3) and zt = R12^T t per observation.
+template <typename T>
+__global__ __launch_bounds__(256) void k_elim_qr_obs(int K, int Ml, const int *__restrict__ obs_pt, const T *__restrict__ Jc,
+                                                     const T *__restrict__ Qw, const T *__restrict__ tvec, T *__restrict__ rec)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const int j = obs_pt[i];
+    T Q[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) Q[q] = Qw[(size_t)q * K + i];
+    const T t0 = tvec[j], t1 = tvec[(size_t)Ml + j], t2 = tvec[2 * (size_t)Ml + j];
+    T *o = rec + (size_t)i * BA_REC;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
+        const T z0 = a0 * Q[0] + a1 * Q[3], z1 = a0 * Q[1] + a1 * Q[4], z2 = a0 * Q[2] + a1 * Q[5];
+        o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
+        o[27 + c] = z0 * t0 + z1 * t1 + z2 * t2;
+    }
+}
+
+// ---- K5: Schur complement / reduced camera matrix, pair-owner form -------------------------------------------
+// S_ab = delta_ab (lambda I + sum A^T A) - sum_j Z_a diag(dinv_j) Z_b^T  (src/Eigen_ext/BacktrackLevMarqQRChol.h:334-341:
+// J2bot^T J2bot; src/Eigen_ext/BacktrackLevMarqCholesky.h:274-278: the Schur complement inside the LDL^T).
+// One 32-lane group per chunk of <= chunk_len entries of one camera pair (two chunks per wavefront); lane
+// (c, q) = (sub / 3, sub % 3) owns the outputs (c, 3q .. 3q+2) of the 9x9 block.  Self entries (row observation ==
+// column observation, diagonal pairs) also accumulate the reduced-rhs term zt.  No atomics: partial blocks go to a
+// slab and are summed per pair in chunk order by k_schur_reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void k_schur_chunks(int nchunks, int Ml, const int *__restrict__ chunk_ptr,
+                                                      const int *__restrict__ ent_r, const int *__restrict__ ent_c,
+                                                      const int *__restrict__ obs_pt, const T *__restrict__ rec,
+                                                      const T *__restrict__ dinv, T *__restrict__ slab)
+{
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
+    if (g >= nchunks) return;
+    const int c = sub / 3, q = sub - 3 * c;
+    const bool act = sub < 27;
+    T acc0 = 0, acc1 = 0, acc2 = 0, zacc = 0;
+    const int e1 = chunk_ptr[g + 1];
+    for (int e = chunk_ptr[g]; e < e1; e++) {
+        const int ia = ent_r[e], ib = ent_c[e];
+        if (act) {
+            const int j = obs_pt[ia];
+            const T *za = rec + (size_t)ia * BA_REC + 3 * c;
+            const T *zb = rec + (size_t)ib * BA_REC + 9 * q;
+            const T a0 = za[0] * dinv[j], a1 = za[1] * dinv[(size_t)Ml + j], a2 = za[2] * dinv[2 * (size_t)Ml + j];
+            acc0 += a0 * zb[0] + a1 * zb[1] + a2 * zb[2];
+            acc1 += a0 * zb[3] + a1 * zb[4] + a2 * zb[5];
+            acc2 += a0 * zb[6] + a1 * zb[7] + a2 * zb[8];
+            if (sub < 9 && ia == ib) zacc += rec[(size_t)ia * BA_REC + 27 + sub];
+        }
+    }
+    if (act) {
+        T *o = slab + (size_t)g * BA_SLAB;
+        o[9 * c + 3 * q] = acc0; o[9 * c + 3 * q + 1] = acc1; o[9 * c + 3 * q + 2] = acc2;
+        if (sub < 9) o[81 + sub] = zacc;
+    }
+}
+
+// Sum the chunk partials of each pair in chunk order and write the 9x9 block of S (lower block triangle; diagonal
+// blocks in full).  Row D of S receives the reduced rhs, row D+1 the camera gradient g_c (both travel through the
+// same all-reduce as S when the problem is sharded).  lambda I is added later by k_post_reduce (once, after the sum
+// over shards).
+template <typename T>
+__global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld, const int *__restrict__ pair_hi,
+                                                      const int *__restrict__ pair_lo, const int *__restrict__ pair_chunk_ptr,
+                                                      const T *__restrict__ slab, const T *__restrict__ V,
+                                                      const T *__restrict__ gc, T *__restrict__ S)
+{
+    const int idx = blockIdx.x * 192 + threadIdx.x;
+    const int p = idx / BA_SLAB, e = idx - p * BA_SLAB;
+    if (p >= npairs || e >= 90) return;
+    const int hi = pair_hi[p], lo = pair_lo[p];
+    if (e >= 81 && hi != lo) return;
+    T s = 0;
+    const int c1 = pair_chunk_ptr[p + 1];
+    for (int c = pair_chunk_ptr[p]; c < c1; c++) s += slab[(size_t)c * BA_SLAB + e];
+    if (e < 81) {
+        const int rr = e / 9, cc = e - 9 * rr;
+        T v = -s;
+        if (hi == lo) v += V[(size_t)hi * 81 + e];
+        S[(size_t)(9 * lo + cc) * ld + 9 * hi + rr] = v;
+    } else {
+        const int cc = e - 81;
+        const T g = gc[9 * hi + cc];
+        S[(size_t)(9 * hi + cc) * ld + D] = g - s;
+        S[(size_t)(9 * hi + cc) * ld + D + 1] = g;
+    }
+}
+
+// After the (optional) all-reduce: add lambda to the diagonal, copy the summed g_c out of row D+1, clear the
+// augmented rows D+1.. and give the padding a unit diagonal so that the blocked LDL^T can run over whole tiles.
+template <typename T>
+__global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, T lambda, T *__restrict__ S, T *__restrict__ gc_out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Dp) return;
+    T *col = S + (size_t)c * ld;
+    if (c < D) {
+        col[c] += lambda;
+        gc_out[c] = col[D + 1];
+        for (int rr = D + 1; rr < Dp; rr++) col[rr] = 0;
+    } else {
+        for (int rr = c; rr < Dp; rr++) col[rr] = (rr == c) ? (T)1 : (T)0;
+    }
+}
+
+// ---- K7 + K8 (points): back-substitution, point retraction, rho terms ----------------------------------------
+// dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i]))  (src/Eigen_ext/BacktrackLevMarqQRChol.h:343-360);
+// x_test = x + dx_p (src/Optimization/BAFunctor.h:335-338); partial sums of dx^T (lambda dx + JtRes) (:375) and |dx|^2.
+template <typename T>
+__global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__ pt_ptr, const int *__restrict__ obs_cam,
+                                                 const T *__restrict__ rec, const T *__restrict__ dinv, const T *__restrict__ tvec,
+                                                 const T *__restrict__ tri, const T *__restrict__ dxc, const T *__restrict__ gp,
+                                                 const T *__restrict__ pts, T lambda, T *__restrict__ dxp, T *__restrict__ pts_test,
+                                                 T *__restrict__ partial /* [2][grid] */)
+{
+    __shared__ T red[4];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    T rho = 0, dn = 0;
+    if (j < Ml) {
+        T u0 = tvec[j], u1 = tvec[(size_t)Ml + j], u2 = tvec[2 * (size_t)Ml + j];
+        const int e = pt_ptr[j + 1];
+        for (int i = pt_ptr[j]; i < e; i++) {
+            const T *Z = rec + (size_t)i * BA_REC;
+            const T *dc = dxc + 9 * obs_cam[i];
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const T d = dc[c];
+                u0 -= Z[3 * c] * d; u1 -= Z[3 * c + 1] * d; u2 -= Z[3 * c + 2] * d;
+            }
+        }
+        u0 *= dinv[j]; u1 *= dinv[(size_t)Ml + j]; u2 *= dinv[2 * (size_t)Ml + j];
+        const T x2 = u2 / tri[5 * (size_t)Ml + j];
+        const T x1 = (u1 - tri[4 * (size_t)Ml + j] * x2) / tri[3 * (size_t)Ml + j];
+        const T x0 = (u0 - tri[(size_t)Ml + j] * x1 - tri[2 * (size_t)Ml + j] * x2) / tri[j];
+        dxp[j] = x0; dxp[(size_t)Ml + j] = x1; dxp[2 * (size_t)Ml + j] = x2;
+        pts_test[j] = pts[j] + x0;
+        pts_test[(size_t)Ml + j] = pts[(size_t)Ml + j] + x1;
+        pts_test[2 * (size_t)Ml + j] = pts[2 * (size_t)Ml + j] + x2;
+        rho = x0 * (lambda * x0 + gp[j]) + x1 * (lambda * x1 + gp[(size_t)Ml + j]) + x2 * (lambda * x2 + gp[2 * (size_t)Ml + j]);
+        dn = x0 * x0 + x1 * x1 + x2 * x2;
+    }
+    rho = block_reduce<T, false>(rho, red);
+    dn = block_reduce<T, false>(dn, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = rho; partial[gridDim.x + blockIdx.x] = dn; }
+}
+
+// ---- K8 (cameras): BAFunctor::update_params (src/Optimization/BAFunctor.h:311-332) -----------------------------
+// T += dT; R <- Rodrigues(d omega) R (identity when |d omega| <= 1e-6, src/MathUtils.h:66-82); f, k1, k2 += .
+// Single block (N <= a few thousand cameras); also the camera part of the rho / |dx|^2 sums -> scal[dst..dst+1].
+template <typename T>
+__global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc,
+                                                      const T *__restrict__ gc, T lambda, T *__restrict__ cam_test,
+                                                      T *__restrict__ scal, int dst)
+{
+    __shared__ T red[4];
+    T rho = 0, dn = 0;
+    for (int a = threadIdx.x; a < N; a += 256) {
+        T p[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            p[c] = dxc[9 * a + c];
+            rho += p[c] * (lambda * p[c] + gc[9 * a + c]);
+            dn += p[c] * p[c];
+        }
+        T R0[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) R0[c] = cam[(size_t)c * N + a];
+        const T th = tsqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5]);
+        T dR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th > (T)1e-6) {
+            const T J[9] = {0, -p[5], p[4], p[5], 0, -p[3], -p[4], p[3], 0};
+            const T c1 = tsin(th) / th, c2 = ((T)1.0 - tcos(th)) / (th * th);
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    T j2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) j2 += J[3 * rr + k] * J[3 * k + cc];
+                    dR[3 * rr + cc] = dR[3 * rr + cc] + c1 * J[3 * rr + cc] + c2 * j2;
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                T s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) s += dR[3 * rr + k] * R0[3 * k + cc];
+                cam_test[(size_t)(3 * rr + cc) * N + a] = s;
+            }
+#pragma unroll
+        for (int c = 0; c < 3; c++) cam_test[(size_t)(9 + c) * N + a] = cam[(size_t)(9 + c) * N + a] + p[c];
+        cam_test[(size_t)12 * N + a] = cam[(size_t)12 * N + a] + p[6];
+        cam_test[(size_t)13 * N + a] = cam[(size_t)13 * N + a] + p[7];
+        cam_test[(size_t)14 * N + a] = cam[(size_t)14 * N + a] + p[8];
+    }
+    rho = block_reduce<T, false>(rho, red);
+    dn = block_reduce<T, false>(dn, red);
+    if (threadIdx.x == 0) { scal[dst] = rho; scal[dst + 1] = dn; }
+}
+
+#endif

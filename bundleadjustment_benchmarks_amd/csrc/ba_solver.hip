@@ -1,0 +1,725 @@
+// ba_solver.hip -- device-resident LM solver behind the C ABI of include/ba_mi355x.h.
+//
+// Host control flow = the LM classes of the reference:
+//   src/Eigen_ext/BacktrackLevMarqQRChol.h:204-436   (QRCHOL; QRKIT reuses the loop)
+//   src/Eigen_ext/BacktrackLevMarqCholesky.h:190-361 (CHOLESKY)
+// Everything the loops call on the functor / linear solver runs as HIP kernels on resident data; per trial only
+// a handful of scalars (test energy, rho denominator, |dx|^2) cross PCIe.
+// There is NO CPU fallback: without a HIP device ba_solver_create fails with BA_ERR_HIP.
+#include "ba_internal.h"
+#include "ba_kernels.hip.h"
+#include "ba_dense.hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            fprintf(stderr, "ba_mi355x: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return BA_ERR_HIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+namespace {
+
+constexpr int NB = 64;       // block-column width of the dense LDL^T
+constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 = spare
+constexpr int NSCAL = 16;    // device scalar slots
+enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
+       SC_ST0 = 8 /* ..11 stats */ };
+enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_N };
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        n = count;
+        if (count == 0) return BA_OK;
+        hipError_t e = hipMalloc((void **)&p, sizeof(T) * count);
+        if (e != hipSuccess) { p = nullptr; return e == hipErrorOutOfMemory ? BA_ERR_NOMEM : BA_ERR_HIP; }
+        return BA_OK;
+    }
+    int upload(const std::vector<T> &h)
+    {
+        int rc = alloc(h.size());
+        if (rc) return rc;
+        if (!h.empty() && hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return BA_ERR_HIP;
+        return BA_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct SolverBase {
+    virtual ~SolverBase() {}
+    virtual int init(const ba_problem *p, ba_solver_kind kind, int rank, int world) = 0;
+    virtual int linearize(double *energy, double *diag_max) = 0;
+    virtual int try_step(double lambda, double *e_test, double *rho_scale, double *dx_norm) = 0;
+    virtual int accept() = 0;
+    virtual int stats(double *out4) = 0;
+    virtual int get(int what, double *out, size_t n) = 0;
+    virtual int set_state(const double *cam15, const double *pts) = 0;
+    virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
+    virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
+    ba_allreduce_fn ar_fn = nullptr;
+    void *ar_user = nullptr;
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    bool keep = false; // keep a copy of S / rhs before the factorisation (parity tests)
+    ba_structure sx;
+    ba_timing tm{};
+    int rank = 0, world = 1;
+};
+
+template <typename T> void host_rodrigues(const T *om, T *R)
+{
+    // Math::createRotationMatrixRodrigues, src/MathUtils.h:66-82
+    const T th = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? (T)1 : (T)0;
+    if (std::fabs(th) > (T)1e-6) {
+        const T J[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+        T J2[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                T a = 0;
+                for (int k = 0; k < 3; k++) a += J[i * 3 + k] * J[k * 3 + j];
+                J2[i * 3 + j] = a;
+            }
+        const T c1 = std::sin(th) / th, c2 = ((T)1.0 - std::cos(th)) / (th * th);
+        for (int i = 0; i < 9; i++) R[i] = R[i] + c1 * J[i] + c2 * J2[i];
+    }
+}
+
+template <typename T> struct Solver final : SolverBase {
+    ba_solver_kind kind = BA_CHOLESKY;
+    int N = 0, D = 0, Dp = 0, ld = 0, Ml = 0, Kl = 0;
+    T tau = (T)0.5; // INLIER_THRESHOLD, src/bundle_adjustment_large.cpp:36
+    // structure
+    DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
+        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
+    // state and work arrays
+    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
+        d_Qw, d_Vw, d_Qlam, d_slab, d_S, d_Skeep, d_Wp, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
+    int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
+    T h_scal[NSCAL];
+    hipEvent_t ev[EV_N] = {};
+    int gK = 0, gM = 0; // grids
+    bool have_step = false;
+
+    ~Solver() override
+    {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (own_stream && st) (void)hipStreamDestroy(st);
+    }
+
+    int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
+    {
+        kind = k; rank = rk; world = wd;
+        int rc = ba_build_structure(p, rk, wd, 32, &sx);
+        if (rc) return rc;
+        N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
+        Dp = ((D + NAUG + NB - 1) / NB) * NB;
+        ld = Dp + 64;
+        gK = (Kl + 255) / 256; gM = (Ml + 255) / 256;
+        if (gK < 1) gK = 1;
+        if (gM < 1) gM = 1;
+        if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
+        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+#define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
+        UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
+        UP(d_pair_lo, sx.pair_lo); UP(d_ent_r, sx.ent_r); UP(d_ent_c, sx.ent_c); UP(d_chunk_ptr, sx.chunk_ptr);
+        UP(d_pair_chunk_ptr, sx.pair_chunk_ptr); UP(d_dchunk_ptr, sx.dchunk_ptr); UP(d_cam_dchunk_ptr, sx.cam_dchunk_ptr);
+        UP(d_cam_obs, sx.cam_obs);
+#undef UP
+        // parameters: bundle_adjustment_large.cpp:81-107 (K00 = -f, R = Rodrigues(omega), distortion (k1 f^2, k2 f^4))
+        std::vector<T> cam((size_t)15 * N), pts((size_t)3 * (Ml > 0 ? Ml : 1)), meas((size_t)2 * (Kl > 0 ? Kl : 1));
+        for (int i = 0; i < N; i++) {
+            const double *c = &p->cams9[9 * (size_t)i];
+            T om[3] = {(T)c[0], (T)c[1], (T)c[2]}, R[9];
+            host_rodrigues<T>(om, R);
+            for (int q = 0; q < 9; q++) cam[(size_t)q * N + i] = R[q];
+            for (int q = 0; q < 3; q++) cam[(size_t)(9 + q) * N + i] = (T)c[3 + q];
+            const T f = (T)c[6], k1 = (T)c[7], k2 = (T)c[8], f2 = f * f;
+            cam[(size_t)12 * N + i] = -f / (T)1.0;
+            cam[(size_t)13 * N + i] = k1 * f2;
+            cam[(size_t)14 * N + i] = k2 * f2 * f2;
+        }
+        for (int j = 0; j < Ml; j++)
+            for (int q = 0; q < 3; q++) pts[(size_t)q * Ml + j] = (T)p->pts[3 * (size_t)(sx.p0 + j) + q];
+        for (int i = 0; i < Kl; i++) {
+            const int src = sx.perm[sx.o0 + i];
+            meas[i] = (T)p->meas[2 * (size_t)src];              // / avg_focal_length (= 1.0, :35,72)
+            meas[(size_t)Kl + i] = (T)p->meas[2 * (size_t)src + 1];
+        }
+        if ((rc = d_cam[0].upload(cam)) || (rc = d_cam[1].upload(cam)) || (rc = d_pts[0].upload(pts)) ||
+            (rc = d_pts[1].upload(pts)) || (rc = d_meas.upload(meas)))
+            return rc;
+        const size_t K1 = Kl > 0 ? Kl : 1, M1 = Ml > 0 ? Ml : 1;
+#define AL(buf, n) if ((rc = buf.alloc(n))) return rc
+        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
+        AL(d_gc, (size_t)D); AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
+        AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
+        if (kind != BA_CHOLESKY) { AL(d_Qw, 6 * K1); AL(d_Vw, 6 * K1); }
+        if (kind == BA_QRKIT) { AL(d_Qlam, 9 * M1); }
+        AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
+        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)ld * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
+        AL(d_part_bs, (size_t)2 * gM); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
+#undef AL
+        HIPCHK(hipMemset(d_S.p, 0, sizeof(T) * d_S.n));
+        HIPCHK(hipMemset(d_Wp.p, 0, sizeof(T) * d_Wp.n));
+        HIPCHK(hipMemset(d_scal.p, 0, sizeof(T) * NSCAL));
+        HIPCHK(hipMemset(d_dxc.p, 0, sizeof(T) * d_dxc.n));
+        HIPCHK(hipDeviceSynchronize());
+        return BA_OK;
+    }
+
+    int allreduce(void *buf, size_t count, int op)
+    {
+        if (world <= 1) return BA_OK;
+        if (!ar_fn) return BA_ERR_COMM;
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = ar_fn(ar_user, buf, count, sizeof(T) == 8 ? BA_F64 : BA_F32, op, (void *)st);
+        tm.comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc ? BA_ERR_COMM : BA_OK;
+    }
+
+    int fetch_scalars()
+    {
+        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, sizeof(T) * NSCAL, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return BA_OK;
+    }
+
+    double ev_ms(int a, int b)
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) return 0;
+        return ms;
+    }
+
+    void launch_eval(bool jac, int which)
+    {
+        const T tau2 = tau * tau;
+        if (jac)
+            hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_part_e.p);
+        else
+            hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p);
+    }
+
+    void launch_grad()
+    {
+        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p,
+                           d_part_pm.p);
+        if (sx.ndchunks > 0)
+            hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks * 32 + 255) / 256), dim3(256), 0, st, sx.ndchunks, Kl,
+                               d_dchunk_ptr.p, d_cam_obs.p, d_Jc.p, d_r.p, d_dslab.p);
+        hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
+                           d_dslab.p, d_V.p, d_gc.p);
+    }
+
+    // m_functor(x, r); energy; m_functor.df(x, J); JtRes; column norms (BacktrackLevMarqQRChol.h:257-280)
+    int linearize(double *energy, double *diag_max) override
+    {
+        int rc;
+        HIPCHK(hipEventRecord(ev[EV_T0], st));
+        launch_eval(true, cur);
+        launch_grad();
+        ba_red_jobs jobs{};
+        int nj = 0;
+        jobs.j[nj++] = {d_part_e.p, gK, 0, SC_ENERGY};
+        if (diag_max) {
+            // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
+            T *tmp = d_dxc.p;
+            hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V.p, tmp);
+            if ((rc = allreduce(tmp, (size_t)D, 0))) return rc;
+            jobs.j[nj++] = {d_part_pm.p, gM, 1, SC_DMAX_P};
+            jobs.j[nj++] = {tmp, D, 1, SC_DMAX_C};
+        }
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p);
+        HIPCHK(hipEventRecord(ev[EV_T1], st));
+        if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
+        if (diag_max && (rc = allreduce(d_scal.p + SC_DMAX_P, 1, 1))) return rc;
+        if ((rc = fetch_scalars())) return rc;
+        HIPCHK(hipGetLastError());
+        tm.linearize_ms += ev_ms(EV_T0, EV_T1);
+        tm.n_linearize++;
+        if (energy) *energy = (double)h_scal[SC_ENERGY];
+        if (diag_max) *diag_max = std::max((double)h_scal[SC_DMAX_P], (double)h_scal[SC_DMAX_C]);
+        have_step = false;
+        return BA_OK;
+    }
+
+    void launch_eliminate(T lambda)
+    {
+        if (kind == BA_CHOLESKY) {
+            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
+                               d_U0.p, d_gp.p, lambda, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+        } else {
+            hipLaunchKernelGGL((k_elim_qr_point<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, lambda,
+                               d_Qw.p, d_Vw.p, d_dinv.p, d_tvec.p, d_tri.p, d_Qlam.p);
+            hipLaunchKernelGGL((k_elim_qr_obs<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_Jc.p, d_Qw.p, d_tvec.p,
+                               d_rec.p);
+        }
+    }
+
+    void launch_schur()
+    {
+        if (sx.nchunks > 0)
+            hipLaunchKernelGGL((k_schur_chunks<T>), dim3((sx.nchunks * 32 + 255) / 256), dim3(256), 0, st, sx.nchunks, Ml,
+                               d_chunk_ptr.p, d_ent_r.p, d_ent_c.p, d_obs_pt.p, d_rec.p, d_dinv.p, d_slab.p);
+        const long long nthr = (long long)sx.npairs * BA_SLAB;
+        hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, sx.npairs, D, ld,
+                           d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);
+    }
+
+    void launch_factor_solve()
+    {
+        const int nrows = D + 1, ncols = D;
+        const int nblk = (ncols + NB - 1) / NB;
+        for (int p = 0; p < nblk; p++) {
+            const int p0 = p * NB;
+            const int below = nrows - (p0 + NB);
+            const int gp_ = below > 0 ? (below + 255) / 256 : 1;
+            hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(gp_), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+            const int p1 = p0 + NB;
+            if (p1 < ncols) {
+                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                launch_update(dim3(ntj, nti), nrows, ncols, p0);
+            }
+        }
+        for (int p = nblk - 1; p >= 0; p--) {
+            const int p0 = p * NB;
+            int g = (p0 + 15) / 16; // 4 columns per workgroup pass; a few passes each
+            if (g < 1) g = 1;
+            if (g > 1024) g = 1024;
+            hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, d_S.p, d_dxc.p);
+        }
+    }
+    void launch_update(dim3 grid, int nrows, int ncols, int p0);
+
+    void launch_backsub_retract(T lambda)
+    {
+        hipLaunchKernelGGL((k_backsub<T>), dim3(gM), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
+                           d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, lambda, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
+        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, lambda,
+                           d_cam[1 - cur].p, d_scal.p, (int)SC_RHO_C);
+    }
+
+    // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375)
+    int try_step(double lambda_d, double *e_test, double *rho_scale, double *dx_norm) override
+    {
+        const T lambda = (T)lambda_d;
+        int rc;
+        HIPCHK(hipEventRecord(ev[EV_T0], st));
+        launch_eliminate(lambda);
+        HIPCHK(hipEventRecord(ev[EV_T1], st));
+        launch_schur();
+        HIPCHK(hipEventRecord(ev[EV_T2], st));
+        if ((rc = allreduce(d_S.p, (size_t)ld * Dp, 0))) return rc;
+        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
+        if (keep) {
+            if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
+            HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipEventRecord(ev[EV_T3], st));
+        launch_factor_solve();
+        HIPCHK(hipEventRecord(ev[EV_T4], st));
+        launch_backsub_retract(lambda);
+        HIPCHK(hipEventRecord(ev[EV_T5], st));
+        launch_eval(false, 1 - cur);
+        ba_red_jobs jobs{};
+        jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
+        jobs.j[1] = {d_part_bs.p, gM, 0, SC_RHO_P};
+        jobs.j[2] = {d_part_bs.p + gM, gM, 0, SC_DN_P};
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
+        HIPCHK(hipEventRecord(ev[EV_T6], st));
+        if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
+        if ((rc = fetch_scalars())) return rc;
+        HIPCHK(hipGetLastError());
+        tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
+        tm.schur_ms += ev_ms(EV_T1, EV_T2);
+        tm.factor_ms += ev_ms(EV_T3, EV_T4);
+        tm.backsub_ms += ev_ms(EV_T4, EV_T5);
+        tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
+        tm.n_trials++;
+        if (e_test) *e_test = (double)h_scal[SC_ETEST];
+        if (rho_scale) *rho_scale = (double)(h_scal[SC_RHO_P] + h_scal[SC_RHO_C]);
+        if (dx_norm) *dx_norm = std::sqrt((double)(h_scal[SC_DN_P] + h_scal[SC_DN_C]));
+        have_step = true;
+        return BA_OK;
+    }
+
+    int accept() override
+    {
+        if (!have_step) return BA_ERR_ARG;
+        cur = 1 - cur;
+        have_step = false;
+        return BA_OK;
+    }
+
+    int stats(double *out4) override
+    {
+        hipLaunchKernelGGL((k_stats<T>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[cur].p, d_pts[cur].p, d_obs_cam.p,
+                           d_obs_pt.p, d_meas.p, tau, d_part_st.p);
+        ba_red_jobs jobs{};
+        for (int q = 0; q < 4; q++) jobs.j[q] = {d_part_st.p + (size_t)q * gK, gK, 0, SC_ST0 + q};
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(4), dim3(256), 0, st, jobs, d_scal.p);
+        int rc;
+        if ((rc = allreduce(d_scal.p + SC_ST0, 4, 0))) return rc;
+        if ((rc = fetch_scalars())) return rc;
+        const double K = (double)sx.K;
+        // accumulate and divide in Scalar like the reference (Utils.h:24-40)
+        out4[0] = (double)(h_scal[SC_ST0] / (T)K);
+        out4[1] = (double)(h_scal[SC_ST0 + 1] / h_scal[SC_ST0 + 2]);
+        out4[2] = (double)h_scal[SC_ST0 + 2];
+        out4[3] = (double)h_scal[SC_ST0 + 3];
+        return BA_OK;
+    }
+
+    int dl(const T *src, size_t n, std::vector<T> &h)
+    {
+        h.resize(n);
+        HIPCHK(hipStreamSynchronize(st));
+        if (n) HIPCHK(hipMemcpy(h.data(), src, sizeof(T) * n, hipMemcpyDeviceToHost));
+        return BA_OK;
+    }
+
+    int get(int what, double *out, size_t n) override
+    {
+        std::vector<T> h, h2;
+        int rc;
+        switch (what) {
+        case BA_GET_RESIDUALS: {
+            if (n != 2 * (size_t)Kl) return BA_ERR_ARG;
+            if ((rc = dl(d_r.p, 2 * (size_t)Kl, h))) return rc;
+            // file order inside the shard when the input was sorted; sorted order otherwise (perm documents it)
+            for (int i = 0; i < Kl; i++) { out[2 * (size_t)i] = h[i]; out[2 * (size_t)i + 1] = h[(size_t)Kl + i]; }
+            return BA_OK;
+        }
+        case BA_GET_JC: {
+            if (n != 18 * (size_t)Kl) return BA_ERR_ARG;
+            if ((rc = dl(d_Jc.p, 18 * (size_t)Kl, h))) return rc;
+            for (int i = 0; i < Kl; i++)
+                for (int q = 0; q < 18; q++) out[18 * (size_t)i + q] = h[(size_t)q * Kl + i];
+            return BA_OK;
+        }
+        case BA_GET_JP: {
+            if (n != 6 * (size_t)Kl) return BA_ERR_ARG;
+            if ((rc = dl(d_Jp.p, 6 * (size_t)Kl, h))) return rc;
+            for (int i = 0; i < Kl; i++)
+                for (int q = 0; q < 6; q++) out[6 * (size_t)i + q] = h[(size_t)q * Kl + i];
+            return BA_OK;
+        }
+        case BA_GET_GRAD: {
+            if (n != 3 * (size_t)Ml + D) return BA_ERR_ARG;
+            if ((rc = dl(d_gp.p, 3 * (size_t)Ml, h)) || (rc = dl(d_gc.p, D, h2))) return rc;
+            for (int j = 0; j < Ml; j++)
+                for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
+            for (int c = 0; c < D; c++) out[3 * (size_t)Ml + c] = h2[c];
+            return BA_OK;
+        }
+        case BA_GET_S:
+        case BA_GET_RHS: {
+            if (!d_Skeep.p) return BA_ERR_ARG;
+            if ((rc = dl(d_Skeep.p, d_Skeep.n, h))) return rc;
+            if (what == BA_GET_RHS) {
+                if (n != (size_t)D) return BA_ERR_ARG;
+                for (int c = 0; c < D; c++) out[c] = h[(size_t)c * ld + D];
+            } else {
+                if (n != (size_t)D * D) return BA_ERR_ARG;
+                for (int c = 0; c < D; c++)
+                    for (int rr = c; rr < D; rr++) out[(size_t)c * D + rr] = out[(size_t)rr * D + c] = h[(size_t)c * ld + rr];
+            }
+            return BA_OK;
+        }
+        case BA_GET_DX: {
+            if (n != 3 * (size_t)Ml + D) return BA_ERR_ARG;
+            if ((rc = dl(d_dxp.p, 3 * (size_t)Ml, h)) || (rc = dl(d_dxc.p, D, h2))) return rc;
+            for (int j = 0; j < Ml; j++)
+                for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
+            for (int c = 0; c < D; c++) out[3 * (size_t)Ml + c] = h2[c];
+            return BA_OK;
+        }
+        case BA_GET_CAMS:
+        case BA_GET_CAMS_TEST: {
+            if (n != 15 * (size_t)N) return BA_ERR_ARG;
+            if ((rc = dl(d_cam[what == BA_GET_CAMS ? cur : 1 - cur].p, 15 * (size_t)N, h))) return rc;
+            for (int a = 0; a < N; a++)
+                for (int q = 0; q < 15; q++) out[15 * (size_t)a + q] = h[(size_t)q * N + a];
+            return BA_OK;
+        }
+        case BA_GET_POINTS:
+        case BA_GET_POINTS_TEST: {
+            if (n != 3 * (size_t)Ml) return BA_ERR_ARG;
+            if ((rc = dl(d_pts[what == BA_GET_POINTS ? cur : 1 - cur].p, 3 * (size_t)Ml, h))) return rc;
+            for (int j = 0; j < Ml; j++)
+                for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
+            return BA_OK;
+        }
+        }
+        return BA_ERR_ARG;
+    }
+
+    int set_state(const double *cam15, const double *pts) override
+    {
+        HIPCHK(hipStreamSynchronize(st));
+        if (cam15) {
+            std::vector<T> h((size_t)15 * N);
+            for (int a = 0; a < N; a++)
+                for (int q = 0; q < 15; q++) h[(size_t)q * N + a] = (T)cam15[15 * (size_t)a + q];
+            HIPCHK(hipMemcpy(d_cam[cur].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+        }
+        if (pts && Ml > 0) {
+            std::vector<T> h((size_t)3 * Ml);
+            for (int j = 0; j < Ml; j++)
+                for (int q = 0; q < 3; q++) h[(size_t)q * Ml + j] = (T)pts[3 * (size_t)j + q];
+            HIPCHK(hipMemcpy(d_pts[cur].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+        }
+        have_step = false;
+        return BA_OK;
+    }
+
+    // The LM loop: BacktrackLevMarqQRChol.h:204-436 == BacktrackLevMarqCholesky.h:190-361 (Scalar arithmetic in T).
+    int minimize(const ba_lm_params *lmp, ba_trial_cb cb, void *user, ba_result *out) override
+    {
+        ba_lm_params lm;
+        if (lmp) lm = *lmp; else ba_lm_params_default(&lm);
+        const auto tbeg = std::chrono::steady_clock::now();
+        ba_timing tm0 = tm;
+        if (lm.verbose && rank == 0) {
+            // outputHeader / outputIterHeader, BacktrackLevMarqQRChol.h:65-82
+            printf("############################## Backtrack LevMarq ###############################\n");
+            printf("--------------------------------------------------------------------------------\n");
+            printf(" Iter%15s%15s%15s%15s%15s\n", "Status", "f", "rho", "lambda", "Elapsed");
+            printf("--------------------------------------------------------------------------------\n");
+        }
+        T lambda = (T)lm.lambda_init, lambda_inc = (T)lm.lambda_increase_base;
+        const T lam_min = (T)lm.lambda_min, lam_max = (T)lm.lambda_max, tol_fun = (T)lm.tol_fun;
+        T hist[2] = {0, 0}, energy = 0;
+        int fun_evals = 0, iter = 0, trials = 0, status = BA_RUNNING, rc = BA_OK;
+        bool stop = false;
+        while (true) {
+            iter++;
+            if (iter > lm.max_iter) { status = BA_MAX_ITERS; break; }
+            if (fun_evals > lm.max_fun_ev) { status = BA_TOO_MANY_FUN_EVALS; break; }
+            double e = 0, dmax = 0;
+            if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
+            fun_evals++;
+            energy = (T)e;
+            if (iter == 1) lambda = (T)(1e-12 * dmax); // :278-280 / Cholesky.h:263-265
+            while (true) {
+                if (lm.max_trials > 0 && trials >= lm.max_trials) { stop = true; status = BA_RUNNING; break; }
+                const auto t0 = std::chrono::steady_clock::now();
+                double et = 0, rs = 0, dn = 0;
+                if ((rc = try_step((double)lambda, &et, &rs, &dn))) { stop = true; break; }
+                fun_evals++;
+                const T e_test = (T)et;
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                trials++;
+                if (e_test < energy) {
+                    const T rho = (energy - e_test) / (T)rs;
+                    const T tmv = (T)2.0 * rho - (T)1.0;
+                    const T mul = (T)1.0 - tmv * tmv * tmv;
+                    lambda *= std::max<T>((T)1.0 / (T)3.0, mul);
+                    lambda = std::max<T>(lambda, lam_min);
+                    if (cb) cb(user, iter, 1, (double)energy, (double)rho, (double)lambda, el);
+                    if (lm.verbose && rank == 0)
+                        printf("%5d%15s%15g%15g%15g%14gs\n", iter, "Accepted", (double)energy, (double)rho, (double)lambda, el);
+                    lambda_inc = (T)lm.lambda_increase_base;
+                    energy = e_test;
+                    hist[iter % 2] = energy;
+                    break;
+                } else {
+                    if (cb) cb(user, iter, 0, (double)energy, 0.0, (double)lambda, el);
+                    if (lm.verbose && rank == 0)
+                        printf("%5d%15s%15g%15g%15g%14gs\n", iter, "Rejected", (double)energy, 0.0, (double)lambda, el);
+                    if (lambda > lam_max) { status = BA_EXCEEDED_LAMBDA_MAX; stop = true; break; }
+                    lambda *= lambda_inc;
+                    lambda_inc = std::pow(lambda_inc, (T)1.5);
+                }
+            }
+            if (stop) break;
+            if (iter > 2) {
+                const T maxf = std::max(hist[0], hist[1]);
+                if (std::fabs(energy - maxf) < tol_fun * energy) { status = BA_SUCCESS; break; } // before x = xTest (:419-428)
+            }
+            if ((rc = accept())) break;
+        }
+        if (lm.verbose && rank == 0) printf("--------------------------------------------------------------------------------\n");
+        if (out) {
+            out->status = status; out->iterations = iter; out->trials = trials; out->fun_evals = fun_evals;
+            out->energy = (double)energy; out->lambda = (double)lambda;
+            out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tbeg).count();
+            const long long nt = tm.n_trials - tm0.n_trials, nl = tm.n_linearize - tm0.n_linearize;
+            out->schur_ms = nt ? ((tm.eliminate_ms - tm0.eliminate_ms) + (tm.schur_ms - tm0.schur_ms) + (tm.factor_ms - tm0.factor_ms) +
+                                  (tm.backsub_ms - tm0.backsub_ms)) / nt : 0.0;
+            out->linearize_ms = nl ? (tm.linearize_ms - tm0.linearize_ms) / nl : 0.0;
+        }
+        return rc;
+    }
+
+    int time_phase(int phase, int reps, double lambda_d, double *ms) override
+    {
+        if (reps < 1 || !ms) return BA_ERR_ARG;
+        const T lambda = (T)lambda_d;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventRecord(ev[EV_T0], st));
+        for (int k = 0; k < reps; k++) {
+            switch (phase) {
+            case 0: launch_eval(false, cur); break;
+            case 1: launch_eval(true, cur); launch_grad(); break;
+            case 2: launch_eliminate(lambda); break;
+            case 3: launch_schur(); break;
+            case 4:
+                launch_schur(); // the factorisation is in place: rebuild S first (timed separately by phase 3)
+                hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
+                launch_factor_solve();
+                break;
+            case 5: launch_backsub_retract(lambda); break;
+            default: return BA_ERR_ARG;
+            }
+        }
+        HIPCHK(hipEventRecord(ev[EV_T1], st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        *ms = ev_ms(EV_T0, EV_T1) / reps;
+        have_step = false;
+        return BA_OK;
+    }
+};
+
+template <> void Solver<double>::launch_update(dim3 grid, int nrows, int ncols, int p0)
+{
+    hipLaunchKernelGGL((k_ldlt_update_f64<NB>), grid, dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+}
+template <> void Solver<float>::launch_update(dim3 grid, int nrows, int ncols, int p0)
+{
+    hipLaunchKernelGGL((k_ldlt_update_f32<NB>), grid, dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+}
+
+} // namespace
+
+struct ba_solver {
+    SolverBase *impl = nullptr;
+};
+
+extern "C" {
+
+int ba_device_info(int device, char *name, size_t n, int *cus)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return BA_ERR_HIP;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return BA_ERR_HIP; }
+    if (device >= cnt) return BA_ERR_ARG;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return BA_ERR_HIP;
+    if (name && n) { snprintf(name, n, "%s (%s)", pr.name, pr.gcnArchName); }
+    if (cus) *cus = pr.multiProcessorCount;
+    return BA_OK;
+}
+
+int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar, int device, int shard_rank, int shard_world,
+                     ba_solver **out)
+{
+    if (!p || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return BA_ERR_ARG;
+    if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY) return BA_ERR_ARG;
+    if (scalar != BA_F64 && scalar != BA_F32) return BA_ERR_ARG;
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        fprintf(stderr, "ba_mi355x: no HIP device -- the solver has no CPU path\n");
+        return BA_ERR_HIP;
+    }
+    if (device >= 0) {
+        if (device >= cnt) return BA_ERR_ARG;
+        HIPCHK(hipSetDevice(device));
+    }
+    SolverBase *impl = (scalar == BA_F64) ? (SolverBase *)new (std::nothrow) Solver<double>() : (SolverBase *)new (std::nothrow) Solver<float>();
+    if (!impl) return BA_ERR_NOMEM;
+    int rc = impl->init(p, kind, shard_rank, shard_world);
+    if (rc) { delete impl; return rc; }
+    ba_solver *s = new (std::nothrow) ba_solver;
+    if (!s) { delete impl; return BA_ERR_NOMEM; }
+    s->impl = impl;
+    *out = s;
+    return BA_OK;
+}
+
+void ba_solver_free(ba_solver *s)
+{
+    if (!s) return;
+    delete s->impl;
+    delete s;
+}
+
+int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user)
+{
+    if (!s) return BA_ERR_ARG;
+    s->impl->ar_fn = fn; s->impl->ar_user = user;
+    return BA_OK;
+}
+
+int ba_solver_set_stream(ba_solver *s, void *hip_stream)
+{
+    if (!s) return BA_ERR_ARG;
+    if (s->impl->own_stream && s->impl->st) { (void)hipStreamSynchronize(s->impl->st); (void)hipStreamDestroy(s->impl->st); }
+    s->impl->st = (hipStream_t)hip_stream;
+    s->impl->own_stream = false;
+    return BA_OK;
+}
+
+int ba_solver_keep_intermediates(ba_solver *s, int on)
+{
+    if (!s) return BA_ERR_ARG;
+    s->impl->keep = on != 0;
+    return BA_OK;
+}
+
+int ba_solver_shard(const ba_solver *s, int *p0, int *p1, int *o0, int *o1)
+{
+    if (!s) return BA_ERR_ARG;
+    if (p0) *p0 = s->impl->sx.p0;
+    if (p1) *p1 = s->impl->sx.p1;
+    if (o0) *o0 = s->impl->sx.o0;
+    if (o1) *o1 = s->impl->sx.o1;
+    return BA_OK;
+}
+
+int ba_minimize(ba_solver *s, const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out)
+{
+    return s ? s->impl->minimize(lm, cb, user, out) : BA_ERR_ARG;
+}
+int ba_solver_linearize(ba_solver *s, double *energy, double *diag_max) { return s ? s->impl->linearize(energy, diag_max) : BA_ERR_ARG; }
+int ba_solver_try_step(ba_solver *s, double lambda, double *energy_test, double *rho_scale, double *dx_norm)
+{
+    return s ? s->impl->try_step(lambda, energy_test, rho_scale, dx_norm) : BA_ERR_ARG;
+}
+int ba_solver_accept(ba_solver *s) { return s ? s->impl->accept() : BA_ERR_ARG; }
+int ba_solver_stats(ba_solver *s, double *out4) { return (s && out4) ? s->impl->stats(out4) : BA_ERR_ARG; }
+int ba_solver_get(ba_solver *s, int what, double *out, size_t n) { return (s && out) ? s->impl->get(what, out, n) : BA_ERR_ARG; }
+int ba_solver_set_state(ba_solver *s, const double *cam15, const double *pts) { return s ? s->impl->set_state(cam15, pts) : BA_ERR_ARG; }
+
+int ba_solver_timing(ba_solver *s, ba_timing *out, int reset)
+{
+    if (!s) return BA_ERR_ARG;
+    if (out) *out = s->impl->tm;
+    if (reset) s->impl->tm = ba_timing{};
+    return BA_OK;
+}
+
+int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, double *ms_per_launch)
+{
+    return s ? s->impl->time_phase(phase, reps, lambda, ms_per_launch) : BA_ERR_ARG;
+}
+
+} // extern "C"

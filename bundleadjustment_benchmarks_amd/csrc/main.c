@@ -1,0 +1,95 @@
+/*
+ * main.c -- drop-in for src/bundle_adjustment_large.cpp of jasvob/BundleAdjustment_Benchmarks: same command line
+ * (`<exe> <sparse reconstruction file>`), exit codes (:26-31), stdout protocol (:61-171) and one executable per
+ * solver symbol (-DQRKIT / -DQRCHOL / -DCHOLESKY, src/CMakeLists.txt:95-178); -DBA_SCALAR_FLOAT stands for
+ * `typedef float Scalar;` (src/BATypeUtils.h:6-7).  All work happens behind the C ABI of include/ba_mi355x.h.
+ * Extension: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking).
+ */
+#define _POSIX_C_SOURCE 199309L
+#include "../../include/ba_mi355x.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#if defined(QRKIT)
+#define BA_KIND BA_QRKIT
+#elif defined(QRCHOL)
+#define BA_KIND BA_QRCHOL
+#elif defined(CHOLESKY)
+#define BA_KIND BA_CHOLESKY
+#else
+#error "define one of QRKIT, QRCHOL, CHOLESKY"
+#endif
+
+#ifdef BA_SCALAR_FLOAT
+#define BA_SCALAR BA_F32
+#else
+#define BA_SCALAR BA_F64
+#endif
+
+/* Utils::showErrorStatistics + Utils::showObjective, src/Utils.h:39-40,65 */
+static void show_stats(ba_solver *s, int K)
+{
+    double st[4];
+    if (ba_solver_stats(s, st) != BA_OK) return;
+    printf("Mean reprojection error: %g\n", st[0]);
+    printf("Inlier mean reprojection error: %g (%d / %d inliers)\n", st[1], (int)st[2], K);
+    printf("True objective: %g\n", st[3]);
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc != 2) {
+        fprintf(stderr, "Usage: %s <sparse reconstruction file>\n", argv[0]);
+        return BA_ERR_USAGE;
+    }
+    ba_problem *p = NULL;
+    int rc = ba_problem_load_bal(argv[1], &p);
+    if (rc == BA_ERR_FILE) {
+        fprintf(stderr, "Cannot open %s\n", argv[1]);
+        return BA_ERR_FILE;
+    }
+    if (rc != BA_OK) {
+        fprintf(stderr, "Cannot parse %s: %s\n", argv[1], ba_error_string(rc));
+        return rc;
+    }
+    int N, M, K;
+    ba_problem_dims(p, &N, &M, &K);
+    printf("N(cameras) = %d, M(points) = %d, K(measurements) = %d\n", N, M, K);
+    printf("Reading image measurements...\nDone.\n");
+    printf("Reading cameras params...\nDone.\n");
+    printf("Reading 3D points...\nDone.\n");
+
+    ba_solver *s = NULL;
+    rc = ba_solver_create(p, BA_KIND, BA_SCALAR, -1, 0, 1, &s);
+    if (rc != BA_OK) {
+        fprintf(stderr, "ba_solver_create: %s\n", ba_error_string(rc));
+        ba_problem_free(p);
+        return rc;
+    }
+    show_stats(s, K);
+
+    ba_lm_params lm;
+    ba_lm_params_default(&lm);
+    lm.verbose = 1;
+    if (getenv("BA_MAX_TRIALS")) lm.max_trials = atoi(getenv("BA_MAX_TRIALS"));
+    ba_result res;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    rc = ba_minimize(s, &lm, NULL, NULL, &res);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (rc != BA_OK) {
+        fprintf(stderr, "ba_minimize: %s\n", ba_error_string(rc));
+        ba_solver_free(s);
+        ba_problem_free(p);
+        return rc;
+    }
+    printf("lm.minimize(params) ... %gs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    printf("LM finished with status: %s\n", ba_status_string(res.status));
+
+    show_stats(s, K);
+    ba_solver_free(s);
+    ba_problem_free(p);
+    return BA_OK; /* success even if the LM status is not Success, like the reference (:175) */
+}
