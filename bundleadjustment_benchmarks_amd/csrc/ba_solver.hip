@@ -28,7 +28,7 @@
 
 namespace {
 
-constexpr int NB = 64;       // block-column width of the dense LDL^T
+constexpr int NB = BA_NB;    // block-column width of the dense LDL^T
 constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 = spare
 constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
@@ -105,7 +105,7 @@ template <typename T> struct Solver final : SolverBase {
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
     // state and work arrays
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
-        d_Qw, d_Vw, d_Qlam, d_slab, d_S, d_Skeep, d_Wp, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
+        d_Qw, d_Vw, d_Qlam, d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
     hipEvent_t ev[EV_N] = {};
@@ -169,7 +169,7 @@ template <typename T> struct Solver final : SolverBase {
         if (kind != BA_CHOLESKY) { AL(d_Qw, 6 * K1); AL(d_Vw, 6 * K1); }
         if (kind == BA_QRKIT) { AL(d_Qlam, 9 * M1); }
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
-        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)ld * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gM); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
 #undef AL
@@ -289,12 +289,13 @@ template <typename T> struct Solver final : SolverBase {
         for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB;
             const int below = nrows - (p0 + NB);
-            const int gp_ = below > 0 ? (below + 255) / 256 : 1;
-            hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(gp_), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+            const int gp_ = below > 0 ? (below + 63) / 64 : 1;
+            hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(gp_), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p,
+                               d_Winv.p + (size_t)p * NB * NB);
             const int p1 = p0 + NB;
             if (p1 < ncols) {
                 const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
-                launch_update(dim3(ntj, nti), nrows, ncols, p0);
+                hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
             }
         }
         for (int p = nblk - 1; p >= 0; p--) {
@@ -302,10 +303,10 @@ template <typename T> struct Solver final : SolverBase {
             int g = (p0 + 15) / 16; // 4 columns per workgroup pass; a few passes each
             if (g < 1) g = 1;
             if (g > 1024) g = 1024;
-            hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, d_S.p, d_dxc.p);
+            hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, d_S.p,
+                               d_Winv.p + (size_t)p * NB * NB, d_dxc.p);
         }
     }
-    void launch_update(dim3 grid, int nrows, int ncols, int p0);
 
     void launch_backsub_retract(T lambda)
     {
@@ -597,15 +598,6 @@ template <typename T> struct Solver final : SolverBase {
         return BA_OK;
     }
 };
-
-template <> void Solver<double>::launch_update(dim3 grid, int nrows, int ncols, int p0)
-{
-    hipLaunchKernelGGL((k_ldlt_update_f64<NB>), grid, dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
-}
-template <> void Solver<float>::launch_update(dim3 grid, int nrows, int ncols, int p0)
-{
-    hipLaunchKernelGGL((k_ldlt_update_f32<NB>), grid, dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
-}
 
 } // namespace
 

@@ -138,3 +138,14 @@ int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int
     s->dchunk_ptr.push_back(Kl);
     return BA_OK;
 }
+
+extern "C" int ba_shard_plan(const ba_problem *p, int shard_rank, int shard_world, long long *out8)
+{
+    if (!p || !out8) return BA_ERR_ARG;
+    ba_structure s;
+    int rc = ba_build_structure(p, shard_rank, shard_world, 32, &s);
+    if (rc) return rc;
+    out8[0] = s.p0; out8[1] = s.p1; out8[2] = s.o0; out8[3] = s.o1; out8[4] = s.E; out8[5] = s.nchunks; out8[6] = s.npairs;
+    out8[7] = s.was_sorted ? 1 : 0;
+    return BA_OK;
+}

@@ -73,6 +73,11 @@ int ba_problem_dims(const ba_problem *p, int *N, int *M, int *K);
 /* Copies out the arrays (any pointer may be NULL). */
 int ba_problem_get(const ba_problem *p, int *cam_idx, int *pt_idx, double *meas, double *cams9, double *pts);
 
+/* Host-only view of the static structure ba_solver_create would build for shard `rank` of `world` (no GPU needed):
+ * out8 = {p0, p1, o0, o1, entries, chunks, camera pairs, input_was_sorted_by_point}.  Points are split into contiguous
+ * ranges balanced by observation count; entries are the (point, camera pair) contributions to the reduced matrix. */
+int ba_shard_plan(const ba_problem *p, int shard_rank, int shard_world, long long *out8);
+
 /* ---- solver: device-resident LM state ------------------------------------------------------------------ */
 
 typedef struct ba_solver ba_solver;

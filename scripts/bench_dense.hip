@@ -1,0 +1,108 @@
+// Dev tool: times the dense LDL^T kernels of ba_dense.hip.h on a random SPD matrix (not part of the product).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -DBA_STAMP -I bundleadjustment_benchmarks_amd/csrc scripts/bench_dense.hip -o /tmp/bench_dense
+#ifndef BENCH_NB
+#define BENCH_NB 64
+#endif
+#include "ba_dense.hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+int main(int argc, char **argv)
+{
+    int D = argc > 1 ? atoi(argv[1]) : 2313;
+    constexpr int NB = BENCH_NB; const int Dp = ((D + 3 + NB - 1) / NB) * NB, ld = Dp + 64;
+    std::vector<double> h((size_t)ld * (Dp + 64), 0.0);
+    srand(1);
+    // SPD: A = B B^T / n + I with B random (use a cheap banded + random low-rank construction)
+    std::vector<double> v((size_t)D * 8);
+    for (auto &x : v) x = rand() / (double)RAND_MAX - 0.5;
+    for (int c = 0; c < D; c++)
+        for (int r = c; r < D; r++) {
+            double a = (r == c) ? 4.0 : 0.0;
+            for (int k = 0; k < 8; k++) a += v[(size_t)r * 8 + k] * v[(size_t)c * 8 + k];
+            h[(size_t)c * ld + r] = a;
+        }
+    for (int c = 0; c < D; c++) h[(size_t)c * ld + D] = rand() / (double)RAND_MAX; // rhs row
+    for (int c = D; c < Dp; c++) h[(size_t)c * ld + c] = 1.0;
+    double *S, *Wp, *Winv, *x, *S0;
+    long long *stamps;
+    CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
+    CK(hipMalloc(&Wp, sizeof(double) * (size_t)ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
+    CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
+    CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)ld * NB));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
+    const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
+    float tp = 0, tu = 0, tb = 0, tot = 0;
+    const int reps = 5;
+    for (int rep = 0; rep < reps + 1; rep++) {
+        CK(hipMemcpyAsync(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice, st));
+        CK(hipEventRecord(e0, st));
+        for (int p = 0; p < nblk; p++) {
+            const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
+            hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB);
+            const int p1 = p0 + NB;
+            if (p1 < ncols) {
+                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
+            }
+        }
+        CK(hipEventRecord(e1, st));
+        for (int p = nblk - 1; p >= 0; p--) {
+            const int p0 = p * NB;
+            int g = (p0 + 15) / 16; if (g < 1) g = 1; if (g > 1024) g = 1024;
+            hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x);
+        }
+        CK(hipEventRecord(e2, st));
+        CK(hipStreamSynchronize(st));
+        float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
+        if (rep) { tot += a; tb += b; }
+    }
+    // panel-only and update-only timings at p0 = 0
+    CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < 20; r++) hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3((nrows - NB + 63) / 64), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
+    CK(hipEventRecord(e1, st));
+    for (int r = 0; r < 20; r++) hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(1), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
+    CK(hipEventRecord(e2, st));
+    for (int r = 0; r < 20; r++) { const int nti = (nrows - NB + 63) / 64, ntj = (ncols - NB + 63) / 64; hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp); }
+    CK(hipEventRecord(e3, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&tp, e0, e1)); float tp1; CK(hipEventElapsedTime(&tp1, e1, e2)); CK(hipEventElapsedTime(&tu, e2, e3));
+    printf("D=%d factor %.3f ms  backsweep %.3f ms | panel(p0=0, full grid) %.2f us, panel(1 WG) %.2f us, update(p0=0) %.2f us\n", D, tot / reps, tb / reps,
+           tp / 20 * 1e3, tp1 / 20 * 1e3, tu / 20 * 1e3);
+    // correctness: solve residual
+    CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
+    // (factor once more, cleanly)
+    for (int p = 0; p < nblk; p++) {
+        const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
+        hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB);
+        const int p1 = p0 + NB;
+        if (p1 < ncols) { const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64; hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp); }
+    }
+    for (int p = nblk - 1; p >= 0; p--) { const int p0 = p * NB; int g = (p0 + 15) / 16; if (g < 1) g = 1; hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x); }
+    CK(hipStreamSynchronize(st));
+    std::vector<double> xs(D);
+    CK(hipMemcpy(xs.data(), x, sizeof(double) * D, hipMemcpyDeviceToHost));
+    double rn = 0, bn = 0;
+    for (int r = 0; r < D; r++) {
+        double a = 0;
+        for (int c = 0; c < D; c++) a += (c <= r ? h[(size_t)c * ld + r] : h[(size_t)r * ld + c]) * xs[c];
+        const double b = h[(size_t)r * ld + D];
+        rn += (a - b) * (a - b); bn += b * b;
+    }
+    printf("relative residual |Sx-b|/|b| = %.3e\n", std::sqrt(rn / bn));
+#ifdef BA_STAMP
+    CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(1), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
+    CK(hipStreamSynchronize(st));
+    long long hs[64]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_stamp_acc), sizeof(hs)));
+    for (int w = 0; w < 4; w++)
+        printf("wave %d cycles/pivot: publish %.0f  barrier %.0f  lds-read %.0f  interleaved %.0f  tail %.0f\n", w, hs[8 * w] / 64.0, hs[8 * w + 1] / 64.0,
+               hs[8 * w + 2] / 64.0, hs[8 * w + 3] / 64.0, hs[8 * w + 4] / 64.0);
+#endif
+    return 0;
+}
