@@ -76,167 +76,228 @@ __device__ long long ba_stamp_acc[8 * 8];
 #define BA_STAMP_SEG(i)
 #endif
 
+// LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the
+// compiler must be told that the load below reads what OTHER lanes stored above (it otherwise hoists the load over the
+// lane-predicated store, which is legal for a single thread).
+__device__ __forceinline__ void ba_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double ba_readlane(double v, int lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+__device__ __forceinline__ float ba_readlane(float v, int lane)
+{
+    union { float f; int i; } u;
+    u.f = v;
+    u.i = __builtin_amdgcn_readlane(u.i, lane);
+    return u.f;
+}
+
 // Panel step for block column p0: rows [p0, nrows), pivots [p0, min(p0 + 64, ncols)).
 //   S    : in place; on exit the block column holds L (strictly lower) and D (diagonal)
-//   Wp   : ld x 64, column-major: Y = L D for the rows below the diagonal block (A operand of the trailing update)
+//   Wp   : ld x 64, column-major: Y = L D for the rows below the diagonal block (operand of the trailing update)
 //   Winv : 64 x 64 row-major: W = L11^-1 of this block (for the backward sweep)
 // Grid: one workgroup per 64 rows below the diagonal block (at least one).
+//
+// Every workgroup factors the 64x64 diagonal block itself (it is the critical path; a broadcast would cost a kernel
+// boundary).  The pivot recurrence d_k -> 1/d_k -> l_ik -> d_k+1 is pure latency on this machine (a dependent f64 FMA
+// is ~32 cycles, one wave issues an f64 op every ~9 cycles), so the block is processed in four 16-wide sub-panels:
+//   A1  ONE wave factors the 16x16 diagonal tile in registers (4 entries per lane) and inverts it with the same row
+//       operations; no barriers; the pivot is broadcast with v_readlane so the reciprocal chain (estimate + Newton)
+//       starts before the LDS exchange of the column has finished;
+//   A2  the tiles below (inside the 64x64 block) get Y = X W_ss^T on the matrix cores;
+//   A3  the remaining tiles of the block get the rank-16 update on the matrix cores.
+// W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
+// block need Y = A21 W^T -- a GEMM, also on the matrix cores.
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                                     T *__restrict__ Winv)
 {
-    constexpr int R = NB / 16; // register blocks per dimension (16x16-cyclic ownership)
-    __shared__ T colb[2][NB], roww[2][NB];
-    __shared__ T Wl[NB][NB + 1];
-    __shared__ T dinv[NB];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
+    __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
+    __shared__ T Wl[NB][NB + 1]; // W[row][col]
+    __shared__ T Ys[16][NB + 1]; // unscaled sub-panel Y[col][row]
+    __shared__ T Ts[3][16][17];  // per-wave scratch of the W assembly
+    __shared__ T colx[16], rowx[16], dinv[NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
-    // 16x16-cyclic ownership: element (i, j) = (ty + 16 a, tx + 16 b)
-    T a_[R][R], w_[R][R];
-#pragma unroll
-    for (int a = 0; a < R; a++)
-#pragma unroll
-        for (int b = 0; b < R; b++) {
-            const int i = ty + 16 * a, j = tx + 16 * b;
-            const int lo = min(i, j), hi = max(i, j);
-            a_[a][b] = S[(size_t)(p0 + lo) * ld + p0 + hi]; // mirror the lower triangle
-            w_[a][b] = (i == j) ? (T)1 : (T)0;
-        }
-    // Software-pipelined pivots.  A dependent f64 FMA costs ~32 cycles on gfx950, so the critical chain of one pivot
-    //   d_k -> 1/d_k (estimate + 2 Newton steps) -> l_ik -> column k+1 -> LDS -> barrier -> LDS -> d_k+1
-    // is pure latency.  The 32 rank-1 FMAs per thread (A and W) of pivot k are issued AFTER the barrier of pivot k and
-    // interleaved by hand with the LDS reads and the reciprocal chain of pivot k+1 (the compiler would otherwise
-    // serialise the two), so they fill the stall slots of that chain.  One barrier per pivot, double-buffered LDS,
-    // two register sets for the multipliers (ping-pong, no copies).
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx % NB, c = idx / NB;
+        const int lo = min(r, c), hi = max(r, c);
+        Ad[c][r] = S[(size_t)(p0 + lo) * ld + p0 + hi]; // mirror the lower triangle
+        Wl[c][r] = (T)0;
+    }
+    if (tid < NB) dinv[tid] = (T)0;
+    __syncthreads();
+    typedef typename ba_acc<T>::type acc_t;
     BA_STAMP_DECL
-    struct PV { T l[R], y[R], wk[R], inv; };
-    PV pv0, pv1;
-    auto fetch0 = [&](PV &n) {
-        const T d = colb[0][0];
+    BA_STAMP_GET(st_t0);
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+        const int c0 = 16 * s;
+        const int np = min(16, nb - c0); // pivots in this sub-panel
+        if (np <= 0) break;              // uniform
+        // ---- A1: 16x16 diagonal tile, wave 0, lane (i, q) owns row i, columns 4q .. 4q+3
+        if (wv == 0) {
+            const int i = li, q = lk;
+            T a[4], w[4];
 #pragma unroll
-        for (int a = 0; a < R; a++) n.l[a] = colb[0][ty + 16 * a];
-#pragma unroll
-        for (int b = 0; b < R; b++) { n.y[b] = colb[0][tx + 16 * b]; n.wk[b] = roww[0][tx + 16 * b]; }
-        n.inv = ba_rcp(d);
-#pragma unroll
-        for (int a = 0; a < R; a++) n.l[a] = (ty + 16 * a > 0) ? n.l[a] * n.inv : (T)0;
-#pragma unroll
-        for (int b = 0; b < R; b++) n.y[b] = (tx + 16 * b > 0) ? n.y[b] : (T)0;
-    };
-    auto pivot = [&](const int kb, const int km, const PV &c, PV &n) {
-        const int k = 16 * kb + km, buf = k & 1, kn = k + 1, kmn = kn & 15;
-        // 1. finalise and publish column k+1 of A and row k+1 of W (temporaries; step 3 recomputes the same values)
-        BA_STAMP_GET(st_t0);
-        if (kn < nb) {
-            const int kq = (km < 15) ? kb : (kb < R - 1 ? kb + 1 : R - 1); // register block that holds index k+1
-            if (tx == kmn) {
-#pragma unroll
-                for (int a = 0; a < R; a++) colb[buf ^ 1][ty + 16 * a] = a_[a][kq] - c.l[a] * c.y[kq];
+            for (int c = 0; c < 4; c++) {
+                a[c] = Ad[c0 + 4 * q + c][c0 + i];
+                w[c] = (4 * q + c == i) ? (T)1 : (T)0;
             }
-            if (ty == kmn) {
 #pragma unroll
-                for (int b = 0; b < R; b++) roww[buf ^ 1][tx + 16 * b] = w_[kq][b] - c.l[kq] * c.wk[b];
+            for (int k = 0; k < 16; k++) {
+                if (k < np) { // uniform
+                    const int kq = k >> 2, kc = k & 3;
+                    if (q == kq) colx[i] = a[kc];
+                    if (i == k) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) rowx[4 * q + c] = w[c];
+                    }
+                    const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
+                    const T r = ba_rcp(dk);
+                    ba_wave_lds_sync();
+                    const T lraw = colx[i];
+                    T y[4], wk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { y[c] = colx[4 * q + c]; wk[c] = rowx[4 * q + c]; }
+                    const T l = (i > k) ? lraw * r : (T)0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (4 * q + c > k) a[c] -= l * y[c]; // 4q + c is lane-dependent: predicated
+                        w[c] -= l * wk[c];
+                    }
+                    if (q == kq && i > k) a[kc] = l;
+                    if (lane == 0) dinv[c0 + k] = r;
+                    ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = 4 * q + c;
+                if (j <= i) Ad[c0 + j][c0 + i] = a[c]; // L (strictly lower) and D (diagonal)
+                Wl[c0 + i][c0 + j] = (j <= i) ? w[c] : (T)0;
             }
         }
+        __syncthreads();
         BA_STAMP_SEG(0);
+        if (s == 3 || c0 + 16 >= NB) break;
+        // ---- A2: tiles below, Y^T = W_ss X^T; wave w takes tile t = s + 1 + w
+        {
+            const int t = s + 1 + wv;
+            if (t < 4) {
+                acc_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[v] = 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const T wa = Wl[c0 + li][c0 + 4 * kk + lk];     // A[j][k] = W_ss[j][k]
+                    const T xb = Ad[c0 + 4 * kk + lk][16 * t + li]; // B[k][n] = X[n][k]
+                    acc = ba_mfma(wa, xb, acc);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int j = ba_crow<T>(lk, v);
+                    const T yv = (j < np) ? acc[v] : (T)0; // columns past the last pivot do not take part
+                    Ys[j][16 * t + li] = yv;
+                    if (j < np) Ad[c0 + j][16 * t + li] = yv * dinv[c0 + j]; // L = Y D^-1
+                }
+            }
+        }
         __syncthreads();
         BA_STAMP_SEG(1);
-        // 2. LDS reads of pivot k+1 (harmless stale data when k+1 == nb)
-        const T dn = colb[buf ^ 1][kn & (NB - 1)];
-#pragma unroll
-        for (int a = 0; a < R; a++) n.l[a] = colb[buf ^ 1][ty + 16 * a];
-#pragma unroll
-        for (int b = 0; b < R; b++) { n.y[b] = colb[buf ^ 1][tx + 16 * b]; n.wk[b] = roww[buf ^ 1][tx + 16 * b]; }
         BA_STAMP_SEG(2);
-        // 3. rank-1 updates of pivot k, interleaved with the reciprocal chain of pivot k+1
-// Only the register blocks that can hold live entries are touched (kb is a compile-time constant of the
-        // unrolled outer loop): A needs rows i > k and columns k < j <= i  ->  blocks a >= b >= kb;
-        // W = L^-1 needs rows i > k and columns j <= k                     ->  blocks a >= kb, b <= kb.
-        // (The loop is issue-bound: one wave issues an f64 FMA only every ~9 cycles, so skipped FMAs are time saved.)
-#define BA_GRP_A(a) { _Pragma("unroll") for (int b = 0; b < R; b++) if (a >= kb && b >= kb && a >= b) a_[a < R ? a : 0][b] -= c.l[a < R ? a : 0] * c.y[b]; }
-#define BA_GRP_W(a) { _Pragma("unroll") for (int b = 0; b < R; b++) if (a >= kb && b <= kb) w_[a < R ? a : 0][b] -= c.l[a < R ? a : 0] * c.wk[b]; }
-        __builtin_amdgcn_sched_barrier(0);
-        BA_GRP_A(0) BA_GRP_W(0)
-        T r = ba_rcp_est(dn);
-        if (R > 1) { BA_GRP_A(1) BA_GRP_W(1) }
-        T e = ba_fnma1(dn, r);
-        if (R > 2) { BA_GRP_A(2) }
-        r = ba_fma_(e, r, r);
-        if (R > 2) { BA_GRP_W(2) }
-        if (sizeof(T) == 8) e = ba_fnma1(dn, r);
-        if (R > 3) { BA_GRP_A(3) }
-        if (sizeof(T) == 8) r = ba_fma_(e, r, r);
-        if (R > 3) { BA_GRP_W(3) }
-        __builtin_amdgcn_sched_barrier(0);
-#undef BA_GRP_A
-#undef BA_GRP_W
+        // ---- A3: rank-16 update of the tiles (ti >= tj > s): C^T[j][i] -= sum_k L[j][k] Y[i][k]
+        {
+            const int nt = 3 - s; // trailing tiles per dimension
+            int cnt = 0;
+            for (int ti = 0; ti < nt; ti++)
+                for (int tj = 0; tj <= ti; tj++, cnt++) {
+                    if ((cnt & 3) != wv) continue;
+                    const int r0 = c0 + 16 + 16 * ti, q0 = c0 + 16 + 16 * tj;
+                    acc_t acc;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[v] = Ad[q0 + ba_crow<T>(lk, v)][r0 + li];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const T la = (4 * kk + lk < np) ? -Ad[c0 + 4 * kk + lk][q0 + li] : (T)0; // A[j][k] = L[j][k]
+                        const T yb = Ys[4 * kk + lk][r0 + li];       // B[k][i] = Y[i][k]
+                        acc = ba_mfma(la, yb, acc);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) Ad[q0 + ba_crow<T>(lk, v)][r0 + li] = acc[v];
+                }
+        }
+        __syncthreads();
         BA_STAMP_SEG(3);
-        n.inv = r;
-#pragma unroll
-        for (int a = 0; a < R; a++) n.l[a] = (ty + 16 * a > kn) ? n.l[a] * r : (T)0;
-#pragma unroll
-        for (int b = 0; b < R; b++) n.y[b] = (tx + 16 * b > kn) ? n.y[b] : (T)0;
-        if (tx == km) {
-#pragma unroll
-            for (int a = 0; a < R; a++)
-                if (ty + 16 * a > k) a_[a][kb] = c.l[a];
-        }
-        if (tx == km && ty == km) dinv[k] = c.inv;
-        BA_STAMP_SEG(4);
-    };
-    if (tx == 0) {
-#pragma unroll
-        for (int a = 0; a < R; a++) colb[0][ty + 16 * a] = a_[a][0];
-    }
-    if (ty == 0) {
-#pragma unroll
-        for (int b = 0; b < R; b++) roww[0][tx + 16 * b] = w_[0][b];
     }
     __syncthreads();
-    fetch0(pv0);
+    BA_STAMP_GET(st_t0);
+    // ---- W = L11^-1: off-diagonal tiles W_ts = -W_tt sum_{u=s}^{t-1} L_tu W_us; wave s builds block column s
+    if (wv < 3 && nb > 16 * (wv + 1)) {
+        const int sc = wv;
+        for (int t = sc + 1; t < 4; t++) {
+            if (16 * t >= nb) break;
+            acc_t acc;
 #pragma unroll
-    for (int kb = 0; kb < R; kb++) {
-#pragma unroll 1
-        for (int km = 0; km < 16; km += 2) { // a real loop: 64 specialised pivot bodies would thrash the instruction cache
-            if (16 * kb + km >= nb) break;
-            pivot(kb, km, pv0, pv1);
-            if (16 * kb + km + 1 >= nb) break;
-            pivot(kb, km + 1, pv1, pv0);
-        }
-    }
-    __syncthreads();
-#ifdef BA_STAMP
-    if (blockIdx.x == 0 && (tid & 63) == 0)
-        for (int q = 0; q < 6; q++) ba_stamp_acc[8 * (tid >> 6) + q] = st_acc[q];
-#endif
-    // publish W (LDS for the GEMM below, global for the backward sweep) and the factored block
+            for (int v = 0; v < 4; v++) acc[v] = 0;
+            for (int u = sc; u < t; u++)
 #pragma unroll
-    for (int a = 0; a < R; a++)
+                for (int kk = 0; kk < 4; kk++) {
+                    const T la = Ad[16 * u + 4 * kk + lk][16 * t + li];  // A[i][k] = L_tu[i][k]
+                    const T wb = Wl[16 * u + 4 * kk + lk][16 * sc + li]; // B[k][j] = W_us[k][j]
+                    acc = ba_mfma(la, wb, acc);
+                }
 #pragma unroll
-        for (int b = 0; b < R; b++) {
-            const int i = ty + 16 * a, j = tx + 16 * b;
-            const T wv = (j <= i && i < nb) ? w_[a][b] : (T)0;
-            Wl[i][j] = wv;
-            if (blockIdx.x == 0) {
-                Winv[i * NB + j] = wv;
-                if (j <= i && j < nb) S[(size_t)(p0 + j) * ld + p0 + i] = a_[a][b];
+            for (int v = 0; v < 4; v++) Ts[sc][ba_crow<T>(lk, v)][li] = acc[v];
+            ba_wave_lds_sync();
+            acc_t acc2;
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc2[v] = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const T wa = -Wl[16 * t + li][16 * t + 4 * kk + lk]; // A[i][k] = -W_tt[i][k]
+                const T tb = Ts[sc][4 * kk + lk][li];                // B[k][j] = T[k][j]
+                acc2 = ba_mfma(wa, tb, acc2);
             }
-        }
-    __syncthreads();
-    // rows below: Y^T = W X^T on the matrix cores; wave w owns 16 rows
-    const int lane = tid & 63, wv_ = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int r0 = p0 + NB + 64 * blockIdx.x + 16 * wv_;
-    if (r0 >= nrows || nb < NB) return;
-    typename ba_acc<T>::type acc[R];
 #pragma unroll
-    for (int t = 0; t < R; t++)
+            for (int v = 0; v < 4; v++) Wl[16 * t + ba_crow<T>(lk, v)][16 * sc + li] = acc2[v];
+            ba_wave_lds_sync(); // W_ts is an operand of the next t; Ts is reused
+        }
+    }
+    __syncthreads();
+    BA_STAMP_SEG(4);
+    // publish the factored block and W (rows >= nb of W are not part of the inverse)
+    for (int idx = tid + 256 * blockIdx.x; idx < NB * NB; idx += 256 * gridDim.x) { // every workgroup writes a slice
+        const int r = idx % NB, c = idx / NB;
+        // The factored diagonal block itself is only read again when it contains the rhs row (last block column,
+        // single workgroup); other workgroups of a wider grid may still be loading the original block from S.
+        if (gridDim.x == 1 && c <= r && c < nb) S[(size_t)(p0 + c) * ld + p0 + r] = Ad[c][r];
+        Winv[c * NB + r] = (r <= c && c < nb) ? Wl[c][r] : (T)0; // here (c, r) = (row, column) of W
+    }
+    // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
+    const int r0 = p0 + NB + 64 * blockIdx.x + 16 * wv;
+    if (r0 >= nrows || nb < NB) return;
+    acc_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[t][v] = 0;
 #pragma unroll
     for (int kk = 0; kk < NB / 4; kk++) {
         const T xb = S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li]; // B[k][n] = X[n][k]
 #pragma unroll
-        for (int t = 0; t < R; t++) {
+        for (int t = 0; t < 4; t++) {
             if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
                 const T wa = Wl[16 * t + li][4 * kk + lk]; // A[j][k]
                 acc[t] = ba_mfma(wa, xb, acc[t]);
@@ -244,7 +305,7 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
         }
     }
 #pragma unroll
-    for (int t = 0; t < R; t++)
+    for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int j = 16 * t + ba_crow<T>(lk, v); // column of the panel
@@ -252,6 +313,11 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
             Wp[(size_t)j * ld + r0 + li] = yv;
             S[(size_t)(p0 + j) * ld + r0 + li] = yv * dinv[j];
         }
+#ifdef BA_STAMP
+    BA_STAMP_SEG(5);
+    if (blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 6; q++) ba_stamp_acc[8 * wv + q] = st_acc[q];
+#endif
 }
 
 // Trailing update.  64 x 64 tile per workgroup; wave w owns a 32 x 32 quadrant (2 x 2 accumulators: two A and two B

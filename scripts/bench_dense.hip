@@ -97,12 +97,12 @@ int main(int argc, char **argv)
     printf("relative residual |Sx-b|/|b| = %.3e\n", std::sqrt(rn / bn));
 #ifdef BA_STAMP
     CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
-    hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(1), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
+    hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(2), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
     CK(hipStreamSynchronize(st));
     long long hs[64]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_stamp_acc), sizeof(hs)));
     for (int w = 0; w < 4; w++)
-        printf("wave %d cycles/pivot: publish %.0f  barrier %.0f  lds-read %.0f  interleaved %.0f  tail %.0f\n", w, hs[8 * w] / 64.0, hs[8 * w + 1] / 64.0,
-               hs[8 * w + 2] / 64.0, hs[8 * w + 3] / 64.0, hs[8 * w + 4] / 64.0);
+        printf("wave %d cycles: A1 %lld  A2 %lld  scale %lld  A3 %lld  Wassembly %lld  publish+phaseB %lld\n", w, hs[8 * w], hs[8 * w + 1],
+               hs[8 * w + 2], hs[8 * w + 3], hs[8 * w + 4], hs[8 * w + 5]);
 #endif
     return 0;
 }
