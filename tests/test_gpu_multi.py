@@ -1,0 +1,101 @@
+"""GPU: the sharded (multi-rank) path end to end on ONE device: two processes, each owning half of the points,
+all-reducing the reduced camera system through the ba_allreduce_fn callback (gloo here, RCCL in bench.py), must
+reproduce the single-rank LM trajectory."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+NTR = 8
+
+
+def _worker(rank, world, port, kind, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import bundleadjustment_benchmarks_amd as ba
+    from bench import DevArray
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        p = ba.Problem.synthetic(24, 3000, 10500, 77)
+        s = ba.Solver(p, kind, ba.F64, device=0, shard_rank=rank, shard_world=world)
+        stream = torch.cuda.current_stream()
+        s.set_stream(stream.cuda_stream)
+
+        def allreduce(ptr, count, scalar, op, strm):
+            t = torch.as_tensor(DevArray(ptr, count, scalar), device=dev)
+            stream.synchronize()
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+            t.copy_(c)
+            stream.synchronize()
+            return 0
+        s.set_allreduce(allreduce)
+        e0, dmax = s.linearize()
+        r = s.minimize(max_trials=NTR)
+        if rank == 0:
+            out_q.put((e0, dmax, r["trace"], r["energy"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.timeout(600)
+def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
+    p = ba.Problem.synthetic(24, 3000, 10500, 77)
+    s = ba.Solver(p, kind, ba.F64)
+    e0, dmax = s.linearize()
+    ref = s.minimize(max_trials=NTR)
+    del s
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() + kind) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    e0s, dmaxs, trace, energy = q.get(timeout=500)
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    assert abs(e0s - e0) < 1e-12 * e0 and abs(dmaxs - dmax) < 1e-12 * dmax
+    assert np.array_equal(trace[:, :2], ref["trace"][:, :2])          # iteration numbers and accept / reject
+    assert np.allclose(trace[:2, 2], ref["trace"][:2, 2], rtol=1e-9)  # energies: the summation order differs across
+    assert np.allclose(trace[:4, 2], ref["trace"][:4, 2], rtol=1e-6)  # shards and the trajectory amplifies it ~10x/iteration
+    assert np.allclose(trace[:, 2], ref["trace"][:, 2], rtol=1e-3)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_allreduce_on_raw_device_pointer(ba, gpu_ok):
+    """bench.py's N > 1 transport on one rank: an RCCL ("nccl") all-reduce of a zero-copy view of raw device memory
+    (the D x D reduced matrix is handed to the callback as pointer + count)."""
+    import torch.distributed as dist
+    from bench import DevArray, make_allreduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29900 + os.getpid() % 90)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.arange(1000, dtype=torch.float64, device=dev)
+        f = torch.arange(10, dtype=torch.float32, device=dev)
+        ar = make_allreduce(torch, dist, dev)
+        assert ar(x.data_ptr() + 8 * 10, 500, 0, 0, 0) == 0
+        assert ar(f.data_ptr(), 10, 1, 1, 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(x, torch.arange(1000, dtype=torch.float64, device=dev))
+        v = torch.as_tensor(DevArray(x.data_ptr() + 80, 5, 0), device=dev)
+        v += 1
+        assert x[10:15].tolist() == [11.0, 12.0, 13.0, 14.0, 15.0]
+    finally:
+        dist.destroy_process_group()
