@@ -102,6 +102,10 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
     return u.f;
 }
 
+template <typename T, int NB, bool TOLDS>
+__device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1]);
+
 // Panel step for block column p0: rows [p0, nrows), pivots [p0, min(p0 + 64, ncols)).
 //   S    : in place; on exit the block column holds L (strictly lower) and D (diagonal)
 //   Wp   : ld x 64, column-major: Y = L D for the rows below the diagonal block (operand of the trailing update)
@@ -119,8 +123,8 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
 // W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
 // block need Y = A21 W^T -- a GEMM, also on the matrix cores.
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
-                                                    T *__restrict__ Winv)
+__device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
+                                              T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel)
 {
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
@@ -138,6 +142,15 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
     }
     if (tid < NB) dinv[tid] = (T)0;
     __syncthreads();
+    if (Wprev) {
+        // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other
+        // workgroups, except for block column p0 itself, which this step needs now: every panel workgroup applies it to
+        // the diagonal block (in LDS, redundantly) and to its own 64 rows below (in S).
+        ba_update_tile<T, NB, true>(ld, p0 - NB, p0, p0, true, S, Wprev, Ad);
+        const int rown = p0 + NB + 64 * blk;
+        if (rown < nrows) ba_update_tile<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr);
+        __syncthreads(); // (s_waitcnt vmcnt(0) + barrier: the S stores above are complete; phase B reads them past L1)
+    }
     typedef typename ba_acc<T>::type acc_t;
     BA_STAMP_DECL
     BA_STAMP_GET(st_t0);
@@ -278,15 +291,15 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
     __syncthreads();
     BA_STAMP_SEG(4);
     // publish the factored block and W (rows >= nb of W are not part of the inverse)
-    for (int idx = tid + 256 * blockIdx.x; idx < NB * NB; idx += 256 * gridDim.x) { // every workgroup writes a slice
+    for (int idx = tid + 256 * blk; idx < NB * NB; idx += 256 * nblk_panel) { // every workgroup writes a slice
         const int r = idx % NB, c = idx / NB;
         // The factored diagonal block itself is only read again when it contains the rhs row (last block column,
         // single workgroup); other workgroups of a wider grid may still be loading the original block from S.
-        if (gridDim.x == 1 && c <= r && c < nb) S[(size_t)(p0 + c) * ld + p0 + r] = Ad[c][r];
+        if (nblk_panel == 1 && c <= r && c < nb) S[(size_t)(p0 + c) * ld + p0 + r] = Ad[c][r];
         Winv[c * NB + r] = (r <= c && c < nb) ? Wl[c][r] : (T)0; // here (c, r) = (row, column) of W
     }
     // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
-    const int r0 = p0 + NB + 64 * blockIdx.x + 16 * wv;
+    const int r0 = p0 + NB + 64 * blk + 16 * wv;
     if (r0 >= nrows || nb < NB) return;
     acc_t acc[4];
 #pragma unroll
@@ -295,7 +308,8 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
         for (int v = 0; v < 4; v++) acc[t][v] = 0;
 #pragma unroll
     for (int kk = 0; kk < NB / 4; kk++) {
-        const T xb = S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li]; // B[k][n] = X[n][k]
+        // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold the pre-update lines
+        const T xb = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
@@ -315,36 +329,73 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
         }
 #ifdef BA_STAMP
     BA_STAMP_SEG(5);
-    if (blockIdx.x == 0 && lane == 0)
+    if (blk == 0 && lane == 0)
         for (int q = 0; q < 6; q++) ba_stamp_acc[8 * wv + q] = st_acc[q];
 #endif
 }
 
-// Trailing update.  64 x 64 tile per workgroup; wave w owns a 32 x 32 quadrant (2 x 2 accumulators: two A and two B
-// fragments feed four MFMAs).  The MFMA computes the TRANSPOSED tile  C^T[j][i] -= sum_k L[j][k] Y[i][k]  so that the
-// 16-wide "column" index of the C/D fragment runs along the rows of S (contiguous in the column-major matrix): every
-// accumulator load / store instruction touches 4 columns x 128 contiguous bytes.  Operands come straight from L2 (the
-// 64-wide panel is a few MB at most); all 8 k-steps of a half are in flight at once to cover the L2 latency.
+
+// Stand-alone panel step (first block column, dense bench).
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int ld, int p0, T *__restrict__ S, const T *__restrict__ Wp)
+__global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
+                                                    T *__restrict__ Winv)
 {
-    const int p1 = p0 + NB;
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = p1 + 64 * ti + 32 * (w >> 1), col0 = p1 + 64 * tj + 32 * (w & 1);
+    ba_panel_body<T, NB>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x);
+}
+
+// Fused step with look-ahead: ONE launch per block column p0 >= 64.
+//   workgroups [0, npanel)        : panel step of block column p0 (after applying the previous panel's update to it);
+//   workgroups [npanel, gridDim.x): the rest of the trailing update of block column p0 - 64 (tiles with columns >= p0 + 64).
+// The two groups touch disjoint parts of S; Wp is double-buffered (Wprev read, Wp written).  The panel's 2313-long pivot
+// recurrence is the critical path of the factorisation; this hides the MFMA update behind it.
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
+                                                   T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv)
+{
+    if ((int)blockIdx.x < npanel) {
+        ba_panel_body<T, NB>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, blockIdx.x, npanel);
+        return;
+    }
+    // tile u of the set {(ti, tj): 1 <= tj <= ti, tj < ntc}, rows p0 + 64 ti, columns p0 + 64 tj
+    const int ntc = (ncols - p0 + 63) / 64;
+    int u = blockIdx.x - npanel, ti = 1;
+    for (;; ti++) {
+        const int cnt = min(ti, ntc - 1);
+        if (u < cnt) break;
+        u -= cnt;
+    }
+    const int tj = 1 + u;
+    const int row0 = p0 + 64 * ti, col0 = p0 + 64 * tj;
     if (row0 >= nrows || col0 >= ncols) return;
-    if (ti == tj && col0 > row0) return; // strictly upper quadrant of a diagonal tile
+    ba_update_tile<T, NB, false>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
+}
+
+// Trailing update of one 64 x 64 tile with the 64-wide panel at block column p0: C_ij -= sum_k Y_ik L_jk.
+// Wave w owns a 32 x 32 quadrant (2 x 2 accumulators: two A and two B fragments feed four MFMAs).  The MFMA computes
+// the TRANSPOSED tile  C^T[j][i] -= sum_k L[j][k] Y[i][k]  so that the 16-wide "column" index of the C/D fragment runs
+// along the rows of S (contiguous in the column-major matrix): every accumulator load / store instruction touches
+// 4 columns x 128 contiguous bytes.  Operands come straight from L2 (the panel is a few MB at most); 8 k-steps are in
+// flight at once to cover the L2 latency.  LOWER: skip the strictly upper quadrant (diagonal tiles).
+// TOLDS: the C tile lives in the LDS image Cl[col][row] (64 x 65) instead of S (diagonal block inside the panel step).
+template <typename T, int NB, bool TOLDS>
+__device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1])
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qr = 32 * (w >> 1), qc = 32 * (w & 1);
+    if (lower && qc > qr) return;
+    const int row0 = row0t + qr, col0 = col0t + qc;
     const int li = lane & 15, lk = lane >> 4;
-    // acc[t][u]: rows of C^T = columns col0 + 16 t + crow of S, cols of C^T = rows row0 + 16 u + li of S
     typename ba_acc<T>::type acc[2][2];
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int v = 0; v < 4; v++)
-                acc[t][u][v] = S[(size_t)(col0 + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + 16 * u + li];
+            for (int v = 0; v < 4; v++) {
+                const int cc = 16 * t + ba_crow<T>(lk, v), rr = 16 * u + li;
+                acc[t][u][v] = TOLDS ? Cl[qc + cc][qr + rr] : S[(size_t)(col0 + cc) * ld + row0 + rr];
+            }
     constexpr int CH = (NB / 4 < 8) ? NB / 4 : 8; // k-steps whose operands are in flight together
 #pragma unroll
     for (int half = 0; half < (NB / 4) / CH; half++) {
@@ -369,8 +420,23 @@ __global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int l
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int v = 0; v < 4; v++)
-                S[(size_t)(col0 + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + 16 * u + li] = acc[t][u][v];
+            for (int v = 0; v < 4; v++) {
+                const int cc = 16 * t + ba_crow<T>(lk, v), rr = 16 * u + li;
+                if (TOLDS) Cl[qc + cc][qr + rr] = acc[t][u][v];
+                else S[(size_t)(col0 + cc) * ld + row0 + rr] = acc[t][u][v];
+            }
+}
+
+// Stand-alone trailing update (one launch per block column; kept for the non-fused path and the dense bench).
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int ld, int p0, T *__restrict__ S, const T *__restrict__ Wp)
+{
+    const int p1 = p0 + NB;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int row0 = p1 + 64 * ti, col0 = p1 + 64 * tj;
+    if (row0 >= nrows || col0 >= ncols) return;
+    ba_update_tile<T, NB, false>(ld, p0, row0, col0, ti == tj, S, Wp, nullptr);
 }
 
 // Backward sweep L^T x = z, right-looking, one launch per block column (p0 descending).  z lives in row zrow of S.

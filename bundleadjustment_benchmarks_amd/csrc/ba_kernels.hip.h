@@ -342,112 +342,114 @@ __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__r
 // The block BlockDiagonalSparseQR factors (src/Optimization/BAFunctor.h:99-105, BAFunctor.cpp:64-68,
 // src/Eigen_ext/BacktrackLevMarqQRChol.h:291-319), rows permuted so that the three sqrt(lambda) rows come first
 // (R and Q1 are unique up to row / column signs, which cancel in S, the reduced rhs and dx), unpivoted.
-// One thread per point; the (2 k_j) x 3 observation rows live in the scratch Qw[6][K]: first B, then the
-// Householder vectors, finally the thin Q1 rows of the observations.
-template <typename T>
-__global__ __launch_bounds__(256) void k_elim_qr_point(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
-                                                       const T *__restrict__ r, T lambda, T *__restrict__ Qw /* [6][K] */,
-                                                       T *__restrict__ Vw /* [6][K] */, T *__restrict__ dinv,
-                                                       T *__restrict__ tvec, T *__restrict__ tri, T *__restrict__ Qlam /* [9][Ml] or null */)
+//
+// LPP lanes work on one point (8 points per wavefront at LPP = 8): lane g of the group holds observations
+// g, g + LPP, ... of the point (up to 4 per lane, 2x3 Jacobian rows each) in registers, so the three Householder
+// reflectors, the thin Q1 = H0 H1 H2 [I3;0] and q1 = Q1^T [0;r] need no memory round trips -- only nine butterfly sums
+// over the LPP lanes.  A thread-per-point loop over observation rows in memory was latency-bound (150 us on 11 k points).
+// The lanes then turn their observations' Q1 rows into Z_i = R12_i^T = A_i^T Q1_i and zt_i = Z_i t.
+template <typename T, int LPP> __device__ __forceinline__ T group_sum(T v)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Ml) return;
-    const int b = pt_ptr[j], e = pt_ptr[j + 1];
-    const T sl = tsqrt(lambda);
-    for (int i = b; i < e; i++)
 #pragma unroll
-        for (int q = 0; q < 6; q++) Vw[(size_t)q * K + i] = Jp[(size_t)q * K + i];
-    // column c of observation row (i, rr) is Vw[3 rr + c][i]
+    for (int off = LPP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPP);
+    return v;
+}
+
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jc,
+                                                 const T *__restrict__ Jp, const T *__restrict__ r, T lambda, T *__restrict__ rec,
+                                                 T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
+{
+    constexpr int SL = 4; // observations per lane: points with up to 4 * LPP observations
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
+    const int j = gid < Ml ? gid : Ml - 1; // idle groups shadow the last point (no early exit: shuffles need every lane)
+    const int b = pt_ptr[j], k = pt_ptr[j + 1] - b;
+    const T sl = tsqrt(lambda);
+    T V[SL][6], Q[SL][6];
+    bool ok[SL];
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+        ok[s] = s * LPP + lg < k;
+        const int i = b + s * LPP + lg;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { V[s][q] = ok[s] ? Jp[(size_t)q * K + i] : (T)0; Q[s][q] = 0; }
+    }
     T R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tau[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         T xn = 0;
-        for (int i = b; i < e; i++) {
-            const T x0 = Vw[(size_t)c * K + i], x1 = Vw[(size_t)(3 + c) * K + i];
-            xn += x0 * x0 + x1 * x1;
-        }
+#pragma unroll
+        for (int s = 0; s < SL; s++) xn += V[s][c] * V[s][c] + V[s][3 + c] * V[s][3 + c];
+        xn = group_sum<T, LPP>(xn);
         const T alpha = sl;                        // the lambda row c is untouched by the earlier reflectors
         const T beta = -tsqrt(alpha * alpha + xn); // alpha > 0
         tau[c] = (beta - alpha) / beta;
         const T sc = (T)1.0 / (alpha - beta);
-        for (int i = b; i < e; i++) {
-            Vw[(size_t)c * K + i] *= sc;
-            Vw[(size_t)(3 + c) * K + i] *= sc;
-        }
+#pragma unroll
+        for (int s = 0; s < SL; s++) { V[s][c] *= sc; V[s][3 + c] *= sc; }
         R[c][c] = beta;
+        T w[3] = {0, 0, 0};
 #pragma unroll
         for (int c2 = c + 1; c2 < 3; c2++) {
-            T w = 0; // the pivot-row entry of column c2 is still zero
-            for (int i = b; i < e; i++)
-                w += Vw[(size_t)c * K + i] * Vw[(size_t)c2 * K + i] + Vw[(size_t)(3 + c) * K + i] * Vw[(size_t)(3 + c2) * K + i];
-            w *= tau[c];
-            R[c][c2] = -w;
-            for (int i = b; i < e; i++) {
-                Vw[(size_t)c2 * K + i] -= Vw[(size_t)c * K + i] * w;
-                Vw[(size_t)(3 + c2) * K + i] -= Vw[(size_t)(3 + c) * K + i] * w;
-            }
+#pragma unroll
+            for (int s = 0; s < SL; s++) w[c2] += V[s][c] * V[s][c2] + V[s][3 + c] * V[s][3 + c2];
+            w[c2] = group_sum<T, LPP>(w[c2]) * tau[c]; // the pivot-row entry of column c2 is still zero
+            R[c][c2] = -w[c2];
+#pragma unroll
+            for (int s = 0; s < SL; s++) { V[s][c2] -= V[s][c] * w[c2]; V[s][3 + c2] -= V[s][3 + c] * w[c2]; }
         }
     }
-    // thin Q1 = H0 H1 H2 [I3; 0]
-    T Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; // lambda rows of Q1
-    for (int i = b; i < e; i++)
-#pragma unroll
-        for (int q = 0; q < 6; q++) Qw[(size_t)q * K + i] = 0;
+    // thin Q1 = H0 H1 H2 [I3; 0]; Ql = its three lambda rows (identical in every lane)
+    T Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
 #pragma unroll
     for (int h = 2; h >= 0; h--) {
+        T w[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            T w = Ql[h][c];
-            for (int i = b; i < e; i++)
-                w += Vw[(size_t)h * K + i] * Qw[(size_t)c * K + i] + Vw[(size_t)(3 + h) * K + i] * Qw[(size_t)(3 + c) * K + i];
-            w *= tau[h];
-            Ql[h][c] -= w;
-            for (int i = b; i < e; i++) {
-                Qw[(size_t)c * K + i] -= Vw[(size_t)h * K + i] * w;
-                Qw[(size_t)(3 + c) * K + i] -= Vw[(size_t)(3 + h) * K + i] * w;
-            }
+            T a = 0;
+#pragma unroll
+            for (int s = 0; s < SL; s++) a += V[s][h] * Q[s][c] + V[s][3 + h] * Q[s][3 + c];
+            w[c] = (Ql[h][c] + group_sum<T, LPP>(a)) * tau[h];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            Ql[h][c] -= w[c];
+#pragma unroll
+            for (int s = 0; s < SL; s++) { Q[s][c] -= V[s][h] * w[c]; Q[s][3 + c] -= V[s][3 + h] * w[c]; }
         }
     }
     // t = -Q1^T [0; r]
     T q1[3] = {0, 0, 0};
-    for (int i = b; i < e; i++) {
-        const T r0 = r[i], r1 = r[(size_t)K + i];
 #pragma unroll
-        for (int c = 0; c < 3; c++) q1[c] += Qw[(size_t)c * K + i] * r0 + Qw[(size_t)(3 + c) * K + i] * r1;
+    for (int s = 0; s < SL; s++) {
+        const int i = b + s * LPP + lg;
+        const T r0 = ok[s] ? r[i] : (T)0, r1 = ok[s] ? r[(size_t)K + i] : (T)0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) q1[c] += Q[s][c] * r0 + Q[s][3 + c] * r1;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        dinv[(size_t)c * Ml + j] = 1;
-        tvec[(size_t)c * Ml + j] = -q1[c];
+    for (int c = 0; c < 3; c++) q1[c] = -group_sum<T, LPP>(q1[c]);
+    if (gid < Ml && lg == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = q1[c]; }
+        tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
+        tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
     }
-    tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
-    tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
-    if (Qlam)
+    // Z_i = A_i^T Q1_i (9x3), zt_i = Z_i t
+    if (gid < Ml) {
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+        for (int s = 0; s < SL; s++) {
+            if (!ok[s]) continue;
+            const int i = b + s * LPP + lg;
+            T *o = rec + (size_t)i * BA_REC;
 #pragma unroll
-            for (int c = 0; c < 3; c++) Qlam[(size_t)(3 * rr + c) * Ml + j] = Ql[rr][c];
-}
-
-// R12_i^T = A_i^T Q1_i (9x3) and zt = R12^T t per observation.
-template <typename T>
-__global__ __launch_bounds__(256) void k_elim_qr_obs(int K, int Ml, const int *__restrict__ obs_pt, const T *__restrict__ Jc,
-                                                     const T *__restrict__ Qw, const T *__restrict__ tvec, T *__restrict__ rec)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K) return;
-    const int j = obs_pt[i];
-    T Q[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) Q[q] = Qw[(size_t)q * K + i];
-    const T t0 = tvec[j], t1 = tvec[(size_t)Ml + j], t2 = tvec[2 * (size_t)Ml + j];
-    T *o = rec + (size_t)i * BA_REC;
-#pragma unroll
-    for (int c = 0; c < 9; c++) {
-        const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
-        const T z0 = a0 * Q[0] + a1 * Q[3], z1 = a0 * Q[1] + a1 * Q[4], z2 = a0 * Q[2] + a1 * Q[5];
-        o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
-        o[27 + c] = z0 * t0 + z1 * t1 + z2 * t2;
+            for (int c = 0; c < 9; c++) {
+                const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
+                const T z0 = a0 * Q[s][0] + a1 * Q[s][3], z1 = a0 * Q[s][1] + a1 * Q[s][4], z2 = a0 * Q[s][2] + a1 * Q[s][5];
+                o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
+                o[27 + c] = z0 * q1[0] + z1 * q1[1] + z2 * q1[2];
+            }
+        }
     }
 }
 
@@ -541,29 +543,34 @@ __global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, T la
 // ---- K7 + K8 (points): back-substitution, point retraction, rho terms ----------------------------------------
 // dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i]))  (src/Eigen_ext/BacktrackLevMarqQRChol.h:343-360);
 // x_test = x + dx_p (src/Optimization/BAFunctor.h:335-338); partial sums of dx^T (lambda dx + JtRes) (:375) and |dx|^2.
-template <typename T>
+template <typename T, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__ pt_ptr, const int *__restrict__ obs_cam,
                                                  const T *__restrict__ rec, const T *__restrict__ dinv, const T *__restrict__ tvec,
                                                  const T *__restrict__ tri, const T *__restrict__ dxc, const T *__restrict__ gp,
                                                  const T *__restrict__ pts, T lambda, T *__restrict__ dxp, T *__restrict__ pts_test,
                                                  T *__restrict__ partial /* [2][grid] */)
 {
+    // LPP lanes per point: each lane forms Z_i^T dx_c for its observations (i = g, g + LPP, ...), a butterfly sum over
+    // the group gives the point's 3-vector, lane 0 of the group finishes the 3x3 triangular solve.
     __shared__ T red[4];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    T rho = 0, dn = 0;
-    if (j < Ml) {
-        T u0 = tvec[j], u1 = tvec[(size_t)Ml + j], u2 = tvec[2 * (size_t)Ml + j];
-        const int e = pt_ptr[j + 1];
-        for (int i = pt_ptr[j]; i < e; i++) {
-            const T *Z = rec + (size_t)i * BA_REC;
-            const T *dc = dxc + 9 * obs_cam[i];
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
+    const int j = gid < Ml ? gid : Ml - 1;
+    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    T s0 = 0, s1 = 0, s2 = 0;
+    for (int i = b + lg; i < e; i += LPP) {
+        const T *Z = rec + (size_t)i * BA_REC;
+        const T *dc = dxc + 9 * obs_cam[i];
 #pragma unroll
-            for (int c = 0; c < 9; c++) {
-                const T d = dc[c];
-                u0 -= Z[3 * c] * d; u1 -= Z[3 * c + 1] * d; u2 -= Z[3 * c + 2] * d;
-            }
+        for (int c = 0; c < 9; c++) {
+            const T d = dc[c];
+            s0 += Z[3 * c] * d; s1 += Z[3 * c + 1] * d; s2 += Z[3 * c + 2] * d;
         }
-        u0 *= dinv[j]; u1 *= dinv[(size_t)Ml + j]; u2 *= dinv[2 * (size_t)Ml + j];
+    }
+    s0 = group_sum<T, LPP>(s0); s1 = group_sum<T, LPP>(s1); s2 = group_sum<T, LPP>(s2);
+    T rho = 0, dn = 0;
+    if (gid < Ml && lg == 0) {
+        const T u0 = (tvec[j] - s0) * dinv[j], u1 = (tvec[(size_t)Ml + j] - s1) * dinv[(size_t)Ml + j],
+                u2 = (tvec[2 * (size_t)Ml + j] - s2) * dinv[2 * (size_t)Ml + j];
         const T x2 = u2 / tri[5 * (size_t)Ml + j];
         const T x1 = (u1 - tri[4 * (size_t)Ml + j] * x2) / tri[3 * (size_t)Ml + j];
         const T x0 = (u0 - tri[(size_t)Ml + j] * x1 - tri[2 * (size_t)Ml + j] * x2) / tri[j];

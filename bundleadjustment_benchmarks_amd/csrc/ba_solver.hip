@@ -105,11 +105,11 @@ template <typename T> struct Solver final : SolverBase {
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
     // state and work arrays
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
-        d_Qw, d_Vw, d_Qlam, d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
+        d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
     hipEvent_t ev[EV_N] = {};
-    int gK = 0, gM = 0; // grids
+    int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
     bool have_step = false;
 
     ~Solver() override
@@ -130,6 +130,9 @@ template <typename T> struct Solver final : SolverBase {
         gK = (Kl + 255) / 256; gM = (Ml + 255) / 256;
         if (gK < 1) gK = 1;
         if (gM < 1) gM = 1;
+        gB = (int)(((size_t)Ml * 8 + 255) / 256);
+        if (gB < 1) gB = 1;
+        if (kind != BA_CHOLESKY && sx.kmax > 256) return BA_ERR_ARG; // more than 256 observations of one point: not supported by k_elim_qr
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
@@ -166,12 +169,10 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
         AL(d_gc, (size_t)D); AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
-        if (kind != BA_CHOLESKY) { AL(d_Qw, 6 * K1); AL(d_Vw, 6 * K1); }
-        if (kind == BA_QRKIT) { AL(d_Qlam, 9 * M1); }
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
-        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)2 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
-        AL(d_part_bs, (size_t)2 * gM); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
+        AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
 #undef AL
         HIPCHK(hipMemset(d_S.p, 0, sizeof(T) * d_S.n));
         HIPCHK(hipMemset(d_Wp.p, 0, sizeof(T) * d_Wp.n));
@@ -265,11 +266,25 @@ template <typename T> struct Solver final : SolverBase {
             hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
                                d_U0.p, d_gp.p, lambda, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            hipLaunchKernelGGL((k_elim_qr_point<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, lambda,
-                               d_Qw.p, d_Vw.p, d_dinv.p, d_tvec.p, d_tri.p, d_Qlam.p);
-            hipLaunchKernelGGL((k_elim_qr_obs<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_Jc.p, d_Qw.p, d_tvec.p,
-                               d_rec.p);
+            launch_elim_qr(lambda);
         }
+    }
+
+    // lanes per point: 8 covers points with up to 32 observations, ... 64 up to 256 (beyond: not supported by the
+    // register kernel -- ba_solver_create refuses such a problem for the QR symbols)
+    int lpp() const { return sx.kmax <= 32 ? 8 : sx.kmax <= 64 ? 16 : sx.kmax <= 128 ? 32 : 64; }
+
+    void launch_elim_qr(T lambda)
+    {
+#define BA_QR(L) hipLaunchKernelGGL((k_elim_qr<T, L>), dim3(((size_t)Ml * L + 255) / 256), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jc.p, \
+                                    d_Jp.p, d_r.p, lambda, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p)
+        switch (lpp()) {
+        case 8: BA_QR(8); break;
+        case 16: BA_QR(16); break;
+        case 32: BA_QR(32); break;
+        default: BA_QR(64); break;
+        }
+#undef BA_QR
     }
 
     void launch_schur()
@@ -286,16 +301,30 @@ template <typename T> struct Solver final : SolverBase {
     {
         const int nrows = D + 1, ncols = D;
         const int nblk = (ncols + NB - 1) / NB;
+        const size_t wsz = (size_t)ld * NB;
         for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB;
             const int below = nrows - (p0 + NB);
-            const int gp_ = below > 0 ? (below + 63) / 64 : 1;
-            hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(gp_), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p,
-                               d_Winv.p + (size_t)p * NB * NB);
-            const int p1 = p0 + NB;
-            if (p1 < ncols) {
-                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
-                hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+            const int npanel = below > 0 ? (below + 63) / 64 : 1;
+            T *wcur = d_Wp.p + (size_t)(p & 1) * wsz, *wprev = d_Wp.p + (size_t)((p + 1) & 1) * wsz;
+            // Look-ahead pays once the trailing update is big enough to be worth hiding (measured: D >= ~2000); for small
+            // matrices the panel's extra update work costs more than the saved launch.
+            const bool fused = nblk >= 24;
+            if (p == 0 || !fused) {
+                hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
+                                   fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB);
+                const int p1 = p0 + NB;
+                if (!fused && p1 < ncols) {
+                    const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                    hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
+                }
+            } else {
+                // trailing tiles of block column p0 - 64 outside block column p0: rows p0 + 64 ti, cols p0 + 64 tj, 1 <= tj <= ti
+                const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
+                int nupd = 0;
+                for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
+                hipLaunchKernelGGL((k_ldlt_step<T, NB>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, d_S.p,
+                                   wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
             }
         }
         for (int p = nblk - 1; p >= 0; p--) {
@@ -310,7 +339,7 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_backsub_retract(T lambda)
     {
-        hipLaunchKernelGGL((k_backsub<T>), dim3(gM), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
+        hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
                            d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, lambda, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
         hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, lambda,
                            d_cam[1 - cur].p, d_scal.p, (int)SC_RHO_C);
@@ -340,8 +369,8 @@ template <typename T> struct Solver final : SolverBase {
         launch_eval(false, 1 - cur);
         ba_red_jobs jobs{};
         jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
-        jobs.j[1] = {d_part_bs.p, gM, 0, SC_RHO_P};
-        jobs.j[2] = {d_part_bs.p + gM, gM, 0, SC_DN_P};
+        jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
+        jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
         hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
         HIPCHK(hipEventRecord(ev[EV_T6], st));
         if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;

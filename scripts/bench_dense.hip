@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 int main(int argc, char **argv)
 {
@@ -29,25 +30,36 @@ int main(int argc, char **argv)
     double *S, *Wp, *Winv, *x, *S0;
     long long *stamps;
     CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
-    CK(hipMalloc(&Wp, sizeof(double) * (size_t)ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
+    CK(hipMalloc(&Wp, sizeof(double) * (size_t)2 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
     CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)ld * NB));
+    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)2 * ld * NB));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
     const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
     float tp = 0, tu = 0, tb = 0, tot = 0;
+    std::vector<double> xs_h(D);
     const int reps = 5;
+    for (int fused = 0; fused < 2; fused++) {
+    tot = 0; tb = 0;
     for (int rep = 0; rep < reps + 1; rep++) {
         CK(hipMemcpyAsync(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
         for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
-            hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB);
-            const int p1 = p0 + NB;
-            if (p1 < ncols) {
-                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
-                hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
+            double *wcur = Wp + (size_t)(p & 1) * ld * NB, *wprev = Wp + (size_t)((p + 1) & 1) * ld * NB;
+            if (p == 0 || !fused) {
+                hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp, Winv + (size_t)p * NB * NB);
+                const int p1 = p0 + NB;
+                if (!fused && p1 < ncols) {
+                    const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                    hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
+                }
+            } else {
+                const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
+                int nupd = 0;
+                for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
+                hipLaunchKernelGGL((k_ldlt_step<double, NB>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
             }
         }
         CK(hipEventRecord(e1, st));
@@ -60,6 +72,10 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
         if (rep) { tot += a; tb += b; }
+    }
+    CK(hipMemcpy(xs_h.data(), x, sizeof(double) * D, hipMemcpyDeviceToHost));
+    { double rn = 0, bn = 0; for (int r = 0; r < D; r++) { double a = 0; for (int c = 0; c < D; c++) a += (c <= r ? h[(size_t)c * ld + r] : h[(size_t)r * ld + c]) * xs_h[c]; const double b = h[(size_t)r * ld + D]; rn += (a - b) * (a - b); bn += b * b; }
+      printf("%s: D=%d factor %.3f ms  backsweep %.3f ms  residual %.2e\n", fused ? "fused look-ahead" : "separate launches", D, tot / reps, tb / reps, std::sqrt(rn / bn)); }
     }
     // panel-only and update-only timings at p0 = 0
     CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
