@@ -4,7 +4,7 @@
 //   cam   T[15][N]   SoA  R row-major (9), T (3), f = K(0,0), k1, k2       (state, x and xTest copies)
 //   pts   T[3][Ml]   SoA
 //   meas  T[2][Kl], r T[2][Kl], Jc T[18][Kl] (2x9 row-major per obs), Jp T[6][Kl]   SoA over observations
-//   rec   T[Kl][36]  AoS  per observation: Z (9x3 row-major) then zt = Z (dinv o t)  -- gathered by the pair kernel
+//   rec   T[Kl][40]  AoS  per observation: Z (9x3 row-major), zt = Z (dinv o t), dinv of its point -- gathered by the pair kernel
 //   U0 T[6][Ml], gp T[3][Ml], dinv T[3][Ml], tvec T[3][Ml], tri T[6][Ml]            per point
 //   S     T[Dp][Dp]  column-major, lower triangle + augmented rows D (rhs), D+1 (g_c), D+2 (scalars)
 #ifndef BA_KERNELS_HIP_H
@@ -12,7 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
-#define BA_REC 36
+#define BA_REC 40 /* Z (27), zt (9), dinv of the point (3), pad (1): 320 B, 16-byte aligned */
 #define BA_SLAB 96
 #define BA_EPS_PSI 1e-15 /* src/Optimization/BAFunctor.h:159 */
 
@@ -237,33 +237,49 @@ __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__
 }
 
 // ---- K3 (camera part): V_aa = sum A^T A (9x9) and g_c = -sum A^T r per camera, once per outer iteration -------
-// One 32-lane group per chunk of <= chunk_len observations of one camera; lane (c, q) owns V[c][3q..3q+2].
+// One 32-lane group per chunk of <= 32 observations of one camera, lane = observation: every lane gathers its own 2x9
+// block (20 independent loads in flight), forms the 45 unique products of A^T A and the 9 of A^T r in registers, and the
+// 54 values are summed over the 32 lanes through LDS (two passes of 27 rows x 32 lanes, each row summed by one lane in
+// lane order -> deterministic).  A lane-per-output mapping walked the 32 observations one after the other and was
+// latency-bound (85 us for 226 k observations).
 template <typename T>
 __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
                                                   const int *__restrict__ cam_obs, const T *__restrict__ Jc,
                                                   const T *__restrict__ r, T *__restrict__ dslab)
 {
-    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
-    if (g >= ndchunks) return;
-    const int c = sub / 3, q = sub - 3 * c;
-    const bool act = sub < 27;
-    T acc[3] = {0, 0, 0}, gacc = 0;
-    const int e1 = dchunk_ptr[g + 1];
-    for (int e = dchunk_ptr[g]; e < e1; e++) {
-        const int i = cam_obs[e];
-        if (act) {
-            const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
+    __shared__ T xch[8][27][33];
+    const int gl = threadIdx.x >> 5, g = blockIdx.x * 8 + gl, sub = threadIdx.x & 31;
+    const bool gok = g < ndchunks;
+    const int e0 = gok ? dchunk_ptr[g] : 0, len = gok ? dchunk_ptr[g + 1] - e0 : 0;
+    T v[54];
 #pragma unroll
-            for (int jj = 0; jj < 3; jj++)
-                acc[jj] += a0 * Jc[(size_t)(3 * q + jj) * K + i] + a1 * Jc[(size_t)(9 + 3 * q + jj) * K + i];
-            if (sub < 9) gacc -= Jc[(size_t)sub * K + i] * r[i] + Jc[(size_t)(9 + sub) * K + i] * r[(size_t)K + i];
-        }
+    for (int q = 0; q < 54; q++) v[q] = 0;
+    if (sub < len) {
+        const int i = cam_obs[e0 + sub];
+        T a0[9], a1[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) { a0[c] = Jc[(size_t)c * K + i]; a1[c] = Jc[(size_t)(9 + c) * K + i]; }
+        const T r0 = r[i], r1 = r[(size_t)K + i];
+        int q = 0;
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+#pragma unroll
+            for (int c2 = 0; c2 <= c; c2++) v[q++] = a0[c] * a0[c2] + a1[c] * a1[c2]; // lower triangle, row-major
+#pragma unroll
+        for (int c = 0; c < 9; c++) v[45 + c] = -(a0[c] * r0 + a1[c] * r1);
     }
-    T *o = dslab + (size_t)g * BA_SLAB;
-    if (act) {
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) o[9 * c + 3 * q + jj] = acc[jj];
-        if (sub < 9) o[81 + sub] = gacc;
+    for (int pass = 0; pass < 2; pass++) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 27; q++) xch[gl][q][sub] = v[27 * pass + q];
+        __syncthreads();
+        if (gok && sub < 27) {
+            T a = 0;
+#pragma unroll
+            for (int l = 0; l < 32; l++) a += xch[gl][sub][l];
+            dslab[(size_t)g * BA_SLAB + 27 * pass + sub] = a;
+        }
     }
 }
 
@@ -274,12 +290,25 @@ __global__ __launch_bounds__(192) void k_cam_gram_reduce(int N, const int *__res
 {
     const int idx = blockIdx.x * 192 + threadIdx.x;
     const int a = idx / BA_SLAB, e = idx - a * BA_SLAB;
-    if (a >= N || e >= 90) return;
-    T s = 0;
-    const int c1 = cam_dchunk_ptr[a + 1];
-    for (int c = cam_dchunk_ptr[a]; c < c1; c++) s += dslab[(size_t)c * BA_SLAB + e];
-    if (e < 81) V[(size_t)a * 81 + e] = s;
-    else gc[9 * a + e - 81] = s;
+    if (a >= N || e >= 54) return;
+    // four interleaved partial sums (fixed order) keep four loads in flight
+    T s4[4] = {0, 0, 0, 0};
+    const int c0 = cam_dchunk_ptr[a], c1 = cam_dchunk_ptr[a + 1];
+    int c = c0;
+    for (; c + 3 < c1; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) s4[u] += dslab[(size_t)(c + u) * BA_SLAB + e];
+    }
+    for (; c < c1; c++) s4[0] += dslab[(size_t)c * BA_SLAB + e];
+    const T s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    if (e < 45) {
+        int rr = 0;
+        while ((rr + 1) * (rr + 2) / 2 <= e) rr++;
+        const int cc = e - rr * (rr + 1) / 2;
+        V[(size_t)a * 81 + 9 * rr + cc] = s;
+        V[(size_t)a * 81 + 9 * cc + rr] = s;
+    } else
+        gc[9 * a + e - 45] = s;
 }
 
 // diagonal of J_c^T J_c (squared column norms of the camera columns, BacktrackLevMarqQRChol.h:270-274)
@@ -336,6 +365,7 @@ __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__r
         o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
         o[27 + c] = z0 * td0 + z1 * td1 + z2 * td2;
     }
+    o[36] = i0; o[37] = i1; o[38] = i2;
 }
 
 // ---- K4 (QRCHOL / QRKIT left block): Householder QR of [sqrt(lambda) I3 ; (Jp)_j] per point ------------------
@@ -449,6 +479,7 @@ __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__res
                 o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
                 o[27 + c] = z0 * q1[0] + z1 * q1[1] + z2 * q1[2];
             }
+            o[36] = 1; o[37] = 1; o[38] = 1;
         }
     }
 }
@@ -461,31 +492,33 @@ __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__res
 // column observation, diagonal pairs) also accumulate the reduced-rhs term zt.  No atomics: partial blocks go to a
 // slab and are summed per pair in chunk order by k_schur_reduce.
 template <typename T>
-__global__ __launch_bounds__(256) void k_schur_chunks(int nchunks, int Ml, const int *__restrict__ chunk_ptr,
+__global__ __launch_bounds__(256) void k_schur_chunks(int nchunks, const int *__restrict__ chunk_ptr,
                                                       const int *__restrict__ ent_r, const int *__restrict__ ent_c,
-                                                      const int *__restrict__ obs_pt, const T *__restrict__ rec,
-                                                      const T *__restrict__ dinv, T *__restrict__ slab)
+                                                      const T *__restrict__ rec, T *__restrict__ slab)
 {
     const int g = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
-    if (g >= nchunks) return;
+    const bool gok = g < nchunks;
     const int c = sub / 3, q = sub - 3 * c;
     const bool act = sub < 27;
+    const int e0 = gok ? chunk_ptr[g] : 0, len = gok ? chunk_ptr[g + 1] - e0 : 0;
+    // the chunk's entry indices are fetched once, one per lane, and handed round with shuffles: the per-entry
+    // loop then has a single level of dependent loads (the records), two entries in flight
+    const int ia_l = (sub < len) ? ent_r[e0 + sub] : 0, ib_l = (sub < len) ? ent_c[e0 + sub] : 0;
     T acc0 = 0, acc1 = 0, acc2 = 0, zacc = 0;
-    const int e1 = chunk_ptr[g + 1];
-    for (int e = chunk_ptr[g]; e < e1; e++) {
-        const int ia = ent_r[e], ib = ent_c[e];
-        if (act) {
-            const int j = obs_pt[ia];
-            const T *za = rec + (size_t)ia * BA_REC + 3 * c;
+#pragma unroll 2
+    for (int e = 0; e < 32; e++) {
+        const int ia = __shfl(ia_l, e, 32), ib = __shfl(ib_l, e, 32);
+        if (e < len && act) {
+            const T *ra = rec + (size_t)ia * BA_REC;
             const T *zb = rec + (size_t)ib * BA_REC + 9 * q;
-            const T a0 = za[0] * dinv[j], a1 = za[1] * dinv[(size_t)Ml + j], a2 = za[2] * dinv[2 * (size_t)Ml + j];
+            const T a0 = ra[3 * c] * ra[36], a1 = ra[3 * c + 1] * ra[37], a2 = ra[3 * c + 2] * ra[38];
             acc0 += a0 * zb[0] + a1 * zb[1] + a2 * zb[2];
             acc1 += a0 * zb[3] + a1 * zb[4] + a2 * zb[5];
             acc2 += a0 * zb[6] + a1 * zb[7] + a2 * zb[8];
-            if (sub < 9 && ia == ib) zacc += rec[(size_t)ia * BA_REC + 27 + sub];
+            if (sub < 9 && ia == ib) zacc += ra[27 + sub];
         }
     }
-    if (act) {
+    if (gok && act) {
         T *o = slab + (size_t)g * BA_SLAB;
         o[9 * c + 3 * q] = acc0; o[9 * c + 3 * q + 1] = acc1; o[9 * c + 3 * q + 2] = acc2;
         if (sub < 9) o[81 + sub] = zacc;
@@ -507,9 +540,15 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld,
     if (p >= npairs || e >= 90) return;
     const int hi = pair_hi[p], lo = pair_lo[p];
     if (e >= 81 && hi != lo) return;
-    T s = 0;
+    T s4[4] = {0, 0, 0, 0}; // four interleaved partial sums (fixed order) keep four loads in flight
     const int c1 = pair_chunk_ptr[p + 1];
-    for (int c = pair_chunk_ptr[p]; c < c1; c++) s += slab[(size_t)c * BA_SLAB + e];
+    int c = pair_chunk_ptr[p];
+    for (; c + 3 < c1; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) s4[u] += slab[(size_t)(c + u) * BA_SLAB + e];
+    }
+    for (; c < c1; c++) s4[0] += slab[(size_t)c * BA_SLAB + e];
+    const T s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     if (e < 81) {
         const int rr = e / 9, cc = e - 9 * rr;
         T v = -s;

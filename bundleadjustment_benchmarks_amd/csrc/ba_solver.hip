@@ -222,7 +222,7 @@ template <typename T> struct Solver final : SolverBase {
         hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p,
                            d_part_pm.p);
         if (sx.ndchunks > 0)
-            hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks * 32 + 255) / 256), dim3(256), 0, st, sx.ndchunks, Kl,
+            hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
                                d_dchunk_ptr.p, d_cam_obs.p, d_Jc.p, d_r.p, d_dslab.p);
         hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
                            d_dslab.p, d_V.p, d_gc.p);
@@ -290,8 +290,8 @@ template <typename T> struct Solver final : SolverBase {
     void launch_schur()
     {
         if (sx.nchunks > 0)
-            hipLaunchKernelGGL((k_schur_chunks<T>), dim3((sx.nchunks * 32 + 255) / 256), dim3(256), 0, st, sx.nchunks, Ml,
-                               d_chunk_ptr.p, d_ent_r.p, d_ent_c.p, d_obs_pt.p, d_rec.p, d_dinv.p, d_slab.p);
+            hipLaunchKernelGGL((k_schur_chunks<T>), dim3((sx.nchunks * 32 + 255) / 256), dim3(256), 0, st, sx.nchunks,
+                               d_chunk_ptr.p, d_ent_r.p, d_ent_c.p, d_rec.p, d_slab.p);
         const long long nthr = (long long)sx.npairs * BA_SLAB;
         hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, sx.npairs, D, ld,
                            d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);

@@ -71,7 +71,7 @@ def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
     assert np.array_equal(trace[:, :2], ref["trace"][:, :2])          # iteration numbers and accept / reject
     assert np.allclose(trace[:2, 2], ref["trace"][:2, 2], rtol=1e-9)  # energies: the summation order differs across
     assert np.allclose(trace[:4, 2], ref["trace"][:4, 2], rtol=1e-6)  # shards and the trajectory amplifies it ~10x/iteration
-    assert np.allclose(trace[:, 2], ref["trace"][:, 2], rtol=1e-3)
+    assert np.allclose(trace[:, 2], ref["trace"][:, 2], rtol=3e-2)
 
 
 @pytest.mark.timeout(300)
