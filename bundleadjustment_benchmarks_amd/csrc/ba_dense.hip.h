@@ -75,6 +75,13 @@ __device__ long long ba_stamp_acc[8 * 8];
 #define BA_STAMP_GET(v)
 #define BA_STAMP_SEG(i)
 #endif
+#ifdef BA_STAMP2
+#define BA_STAMP2_GET(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define BA_STAMP2_SEG(i) { BA_STAMP2_GET(st2_t1); st2_acc[i] += (long long)(st2_t1 - st2_t0); st2_t0 = st2_t1; }
+#else
+#define BA_STAMP2_GET(v)
+#define BA_STAMP2_SEG(i)
+#endif
 
 // LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the
 // compiler must be told that the load below reads what OTHER lanes stored above (it otherwise hoists the load over the
@@ -131,7 +138,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     __shared__ T Wl[NB][NB + 1]; // W[row][col]
     __shared__ T Ys[16][NB + 1]; // unscaled sub-panel Y[col][row]
     __shared__ T Ts[3][16][17];  // per-wave scratch of the W assembly
-    __shared__ T colx[16], rowx[16], dinv[NB];
+    __shared__ T colx4[4][16], wtile[16][17], dinv[NB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -159,48 +166,62 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int c0 = 16 * s;
         const int np = min(16, nb - c0); // pivots in this sub-panel
         if (np <= 0) break;              // uniform
-        // ---- A1: 16x16 diagonal tile, wave 0, lane (i, q) owns row i, columns 4q .. 4q+3
+        // ---- A1: 16x16 diagonal tile, wave 0, lane (i, q) owns row i, columns 4q .. 4q+3.
+        // A single wave issues one f64-class VALU instruction every ~8 cycles, so the loop is written for instruction
+        // count: every LDS store is unconditional (lanes that do not own the datum store to a scratch slot instead of
+        // being masked off), the multipliers leave the registers for LDS as soon as they exist, so the rank-1 update
+        // needs no masks on the already finished columns.
         if (wv == 0) {
             const int i = li, q = lk;
+#ifdef BA_STAMP2
+            unsigned long long st2_t0 = 0, st2_t1 = 0; long long st2_acc[4] = {0, 0, 0, 0};
+#endif
             T a[4], w[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 a[c] = Ad[c0 + 4 * q + c][c0 + i];
                 w[c] = (4 * q + c == i) ? (T)1 : (T)0;
             }
+            T *const junk = &Ts[0][0][0] + lane; // per-lane scratch slot (Ts is not in use before the W assembly)
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < np) { // uniform
                     const int kq = k >> 2, kc = k & 3;
-                    if (q == kq) colx[i] = a[kc];
-                    if (i == k) {
+                    BA_STAMP2_GET(st2_t0);
+                    colx4[q][i] = a[kc];                       // column k is the kc-th register of the lanes with q == kq
 #pragma unroll
-                        for (int c = 0; c < 4; c++) rowx[4 * q + c] = w[c];
-                    }
+                    for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
+                    BA_STAMP2_SEG(0);
                     const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
                     const T r = ba_rcp(dk);
+                    BA_STAMP2_SEG(1);
                     ba_wave_lds_sync();
-                    const T lraw = colx[i];
+                    const T lraw = colx4[kq][i];
                     T y[4], wk[4];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { y[c] = colx[4 * q + c]; wk[c] = rowx[4 * q + c]; }
+                    for (int c = 0; c < 4; c++) { y[c] = colx4[kq][4 * q + c]; wk[c] = wtile[k][4 * q + c]; }
+                    BA_STAMP2_SEG(2);
                     const T l = (i > k) ? lraw * r : (T)0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        if (4 * q + c > k) a[c] -= l * y[c]; // 4q + c is lane-dependent: predicated
+                        a[c] -= l * y[c]; // columns <= k are dead from here on (their multipliers live in Ad)
                         w[c] -= l * wk[c];
                     }
-                    if (q == kq && i > k) a[kc] = l;
-                    if (lane == 0) dinv[c0 + k] = r;
+                    *((q == kq && i > k) ? &Ad[c0 + k][c0 + i] : junk) = l;     // L(i, k)
+                    *((lane == 0) ? &dinv[c0 + k] : junk) = r;
+                    *((lane == 0) ? &Ad[c0 + k][c0 + k] : junk) = dk;           // D(k)
                     ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
+                    BA_STAMP2_SEG(3);
                 }
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int j = 4 * q + c;
-                if (j <= i) Ad[c0 + j][c0 + i] = a[c]; // L (strictly lower) and D (diagonal)
                 Wl[c0 + i][c0 + j] = (j <= i) ? w[c] : (T)0;
             }
+#ifdef BA_STAMP2
+            if (blk == 0 && lane == 0) for (int q2 = 0; q2 < 4; q2++) ba_stamp_acc[32 + 4 * s + q2] = st2_acc[q2];
+#endif
         }
         __syncthreads();
         BA_STAMP_SEG(0);

@@ -309,7 +309,7 @@ template <typename T> struct Solver final : SolverBase {
             T *wcur = d_Wp.p + (size_t)(p & 1) * wsz, *wprev = d_Wp.p + (size_t)((p + 1) & 1) * wsz;
             // Look-ahead pays once the trailing update is big enough to be worth hiding (measured: D >= ~2000); for small
             // matrices the panel's extra update work costs more than the saved launch.
-            const bool fused = nblk >= 24;
+            const bool fused = nblk >= 24 && nblk <= 72; // beyond ~4600 the update needs the occupancy the panel's LDS footprint denies it
             if (p == 0 || !fused) {
                 hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
                                    fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB);
@@ -327,6 +327,8 @@ template <typename T> struct Solver final : SolverBase {
                                    wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
             }
         }
+        // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
+        // measured slower: the column reads are uncoalesced across lanes)
         for (int p = nblk - 1; p >= 0; p--) {
             const int p0 = p * NB;
             int g = (p0 + 15) / 16; // 4 columns per workgroup pass; a few passes each
