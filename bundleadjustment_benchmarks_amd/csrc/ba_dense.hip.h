@@ -138,7 +138,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     __shared__ T Wl[NB][NB + 1]; // W[row][col]
     __shared__ T Ys[16][NB + 1]; // unscaled sub-panel Y[col][row]
     __shared__ T Ts[3][16][17];  // per-wave scratch of the W assembly
-    __shared__ T colx4[4][16], wtile[16][17], dinv[NB];
+    __shared__ T colx4[4][16], wtile[16][17], dinv[NB], junkbuf[64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -161,6 +161,36 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     typedef typename ba_acc<T>::type acc_t;
     BA_STAMP_DECL
     BA_STAMP_GET(st_t0);
+    // Off-diagonal tile W_ts of W = L11^-1 (t > sc): W_ts = -W_tt sum_{u=sc}^{t-1} L_tu W_us, one wave, MFMA products.
+    // Row t only needs rows < t of W, L_tu (final after A2 of sub-panel u) and W_tt (from A1 of sub-panel t), so row t is
+    // built by the otherwise idle waves 1..3 while wave 0 runs A1 of sub-panel t + 1; only the last row is exposed.
+    auto w_tile = [&](int t, int sc, int scratch) {
+        acc_t acc;
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = 0;
+        for (int u = sc; u < t; u++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const T la = Ad[16 * u + 4 * kk + lk][16 * t + li];  // A[i][k] = L_tu[i][k]
+                const T wb = Wl[16 * u + 4 * kk + lk][16 * sc + li]; // B[k][j] = W_us[k][j]
+                acc = ba_mfma(la, wb, acc);
+            }
+#pragma unroll
+        for (int v = 0; v < 4; v++) Ts[scratch][ba_crow<T>(lk, v)][li] = acc[v];
+        ba_wave_lds_sync();
+        acc_t acc2;
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc2[v] = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const T wa = -Wl[16 * t + li][16 * t + 4 * kk + lk]; // A[i][k] = -W_tt[i][k]
+            const T tb = Ts[scratch][4 * kk + lk][li];           // B[k][j] = T[k][j]
+            acc2 = ba_mfma(wa, tb, acc2);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) Wl[16 * t + ba_crow<T>(lk, v)][16 * sc + li] = acc2[v];
+        ba_wave_lds_sync();
+    };
 #pragma unroll 1
     for (int s = 0; s < 4; s++) {
         const int c0 = 16 * s;
@@ -182,7 +212,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 a[c] = Ad[c0 + 4 * q + c][c0 + i];
                 w[c] = (4 * q + c == i) ? (T)1 : (T)0;
             }
-            T *const junk = &Ts[0][0][0] + lane; // per-lane scratch slot (Ts is not in use before the W assembly)
+            T *const junk = junkbuf + lane; // per-lane scratch slot
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < np) { // uniform
@@ -222,6 +252,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #ifdef BA_STAMP2
             if (blk == 0 && lane == 0) for (int q2 = 0; q2 < 4; q2++) ba_stamp_acc[32 + 4 * s + q2] = st2_acc[q2];
 #endif
+        } else if (s >= 2 && wv - 1 < s - 1) {
+            w_tile(s - 1, wv - 1, wv - 1); // row s-1 of W, block column wv-1, while wave 0 factors sub-panel s
         }
         __syncthreads();
         BA_STAMP_SEG(0);
@@ -277,37 +309,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     }
     __syncthreads();
     BA_STAMP_GET(st_t0);
-    // ---- W = L11^-1: off-diagonal tiles W_ts = -W_tt sum_{u=s}^{t-1} L_tu W_us; wave s builds block column s
-    if (wv < 3 && nb > 16 * (wv + 1)) {
-        const int sc = wv;
-        for (int t = sc + 1; t < 4; t++) {
-            if (16 * t >= nb) break;
-            acc_t acc;
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[v] = 0;
-            for (int u = sc; u < t; u++)
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const T la = Ad[16 * u + 4 * kk + lk][16 * t + li];  // A[i][k] = L_tu[i][k]
-                    const T wb = Wl[16 * u + 4 * kk + lk][16 * sc + li]; // B[k][j] = W_us[k][j]
-                    acc = ba_mfma(la, wb, acc);
-                }
-#pragma unroll
-            for (int v = 0; v < 4; v++) Ts[sc][ba_crow<T>(lk, v)][li] = acc[v];
-            ba_wave_lds_sync();
-            acc_t acc2;
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc2[v] = 0;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const T wa = -Wl[16 * t + li][16 * t + 4 * kk + lk]; // A[i][k] = -W_tt[i][k]
-                const T tb = Ts[sc][4 * kk + lk][li];                // B[k][j] = T[k][j]
-                acc2 = ba_mfma(wa, tb, acc2);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) Wl[16 * t + ba_crow<T>(lk, v)][16 * sc + li] = acc2[v];
-            ba_wave_lds_sync(); // W_ts is an operand of the next t; Ts is reused
-        }
+    // ---- the last row of W that has pivots (rows before it were built under A1 of the following sub-panels)
+    {
+        const int tl = (nb - 1) / 16; // last tile row with pivots
+        if (tl >= 1 && wv < tl) w_tile(tl, wv, wv);
     }
     __syncthreads();
     BA_STAMP_SEG(4);
@@ -490,13 +495,23 @@ __global__ __launch_bounds__(256) void k_ldlt_backstep(int ncols, int ld, int zr
         if (blockIdx.x == 0 && tid < nb) x[p0 + tid] = xv;
     }
     __syncthreads();
-    const int lane = tid & 63, w = tid >> 6;
-    const T xl = (lane < NB) ? xs[lane < NB ? lane : 0] : (T)0;
-    for (int c = blockIdx.x * 4 + w; c < p0; c += gridDim.x * 4) {
-        T a = (lane < NB) ? S[(size_t)c * ld + p0 + lane] * xl : (T)0;
+    // elimination from the earlier unknowns: a wave takes 16 columns per pass, lane (cq, rq) sums 16 of the 64 rows of
+    // column cq (128 contiguous bytes), two butterfly steps combine the four row quarters
+    const int lane = tid & 63, w = tid >> 6, cq = lane & 15, rq = lane >> 4;
+    T xr[NB / 4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-        if (lane == 0) S[(size_t)c * ld + zrow] -= a;
+    for (int t = 0; t < NB / 4; t++) xr[t] = xs[(NB / 4) * rq + t];
+    for (int cb = (blockIdx.x * 4 + w) * 16; cb < p0; cb += gridDim.x * 64) {
+        const int c = cb + cq;
+        T a = 0;
+        if (c < p0) {
+            const T *col = S + (size_t)c * ld + p0 + (NB / 4) * rq;
+#pragma unroll
+            for (int t = 0; t < NB / 4; t++) a += col[t] * xr[t];
+        }
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (rq == 0 && c < p0) S[(size_t)c * ld + zrow] -= a;
     }
 }
 

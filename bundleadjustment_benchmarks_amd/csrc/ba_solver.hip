@@ -331,9 +331,8 @@ template <typename T> struct Solver final : SolverBase {
         // measured slower: the column reads are uncoalesced across lanes)
         for (int p = nblk - 1; p >= 0; p--) {
             const int p0 = p * NB;
-            int g = (p0 + 15) / 16; // 4 columns per workgroup pass; a few passes each
+            int g = (p0 + 63) / 64; // 64 columns per workgroup
             if (g < 1) g = 1;
-            if (g > 1024) g = 1024;
             hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, d_S.p,
                                d_Winv.p + (size_t)p * NB * NB, d_dxc.p);
         }

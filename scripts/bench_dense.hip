@@ -65,7 +65,7 @@ int main(int argc, char **argv)
         CK(hipEventRecord(e1, st));
         for (int p = nblk - 1; p >= 0; p--) {
             const int p0 = p * NB;
-            int g = (p0 + 15) / 16; if (g < 1) g = 1; if (g > 1024) g = 1024;
+            int g = (p0 + 63) / 64; if (g < 1) g = 1;
             hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x);
         }
         CK(hipEventRecord(e2, st));
@@ -99,7 +99,7 @@ int main(int argc, char **argv)
         const int p1 = p0 + NB;
         if (p1 < ncols) { const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64; hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp); }
     }
-    for (int p = nblk - 1; p >= 0; p--) { const int p0 = p * NB; int g = (p0 + 15) / 16; if (g < 1) g = 1; hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x); }
+    for (int p = nblk - 1; p >= 0; p--) { const int p0 = p * NB; int g = (p0 + 63) / 64; if (g < 1) g = 1; hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x); }
     CK(hipStreamSynchronize(st));
     std::vector<double> xs(D);
     CK(hipMemcpy(xs.data(), x, sizeof(double) * D, hipMemcpyDeviceToHost));
