@@ -297,7 +297,9 @@ template <typename T> struct Solver final : SolverBase {
                            d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);
     }
 
-    void launch_factor_solve()
+    void launch_factor_solve() { launch_factor(); launch_backsweep(); }
+
+    void launch_factor()
     {
         const int nrows = D + 1, ncols = D;
         const int nblk = (ncols + NB - 1) / NB;
@@ -327,8 +329,14 @@ template <typename T> struct Solver final : SolverBase {
                                    wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
             }
         }
-        // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
-        // measured slower: the column reads are uncoalesced across lanes)
+    }
+
+    // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
+    // measured slower: the column reads are uncoalesced across lanes)
+    void launch_backsweep()
+    {
+        const int ncols = D;
+        const int nblk = (ncols + NB - 1) / NB;
         for (int p = nblk - 1; p >= 0; p--) {
             const int p0 = p * NB;
             int g = (p0 + 63) / 64; // 64 columns per workgroup
@@ -603,6 +611,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (reps < 1 || !ms) return BA_ERR_ARG;
         const T lambda = (T)lambda_d;
+        double acc_ms = 0;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipEventRecord(ev[EV_T0], st));
         for (int k = 0; k < reps; k++) {
@@ -617,13 +626,26 @@ template <typename T> struct Solver final : SolverBase {
                 launch_factor_solve();
                 break;
             case 5: launch_backsub_retract(lambda); break;
+            case 6: // dense factorisation only (k_ldlt_panel + k_ldlt_step / k_ldlt_update): events around it, per rep
+            case 7: // backward sweep only (k_ldlt_backstep)
+                launch_schur();
+                hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
+                if (phase == 6) HIPCHK(hipEventRecord(ev[EV_T2], st));
+                launch_factor();
+                if (phase == 6) HIPCHK(hipEventRecord(ev[EV_T3], st));
+                if (phase == 7) HIPCHK(hipEventRecord(ev[EV_T2], st));
+                launch_backsweep();
+                if (phase == 7) HIPCHK(hipEventRecord(ev[EV_T3], st));
+                HIPCHK(hipStreamSynchronize(st));
+                acc_ms += ev_ms(EV_T2, EV_T3);
+                break;
             default: return BA_ERR_ARG;
             }
         }
         HIPCHK(hipEventRecord(ev[EV_T1], st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
-        *ms = ev_ms(EV_T0, EV_T1) / reps;
+        *ms = (phase >= 6 ? acc_ms : ev_ms(EV_T0, EV_T1)) / reps;
         have_step = false;
         return BA_OK;
     }

@@ -181,7 +181,8 @@ int ba_solver_timing(ba_solver *s, ba_timing *out, int reset);
 
 /* Bench hooks: replay one phase `reps` times on the solver's stream and return the mean device ms per launch
  * (HIP events on that stream).  phase: 0 residual eval, 1 residual+Jacobian, 2 point elimination,
- * 3 Schur assembly, 4 dense factor + solve, 5 back-substitution + retraction. */
+ * 3 Schur assembly, 4 Schur assembly + dense factor + solve, 5 back-substitution + retraction,
+ * 6 dense factorisation only, 7 backward sweep only (6 / 7 rebuild S untimed before every repetition). */
 int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, double *ms_per_launch);
 
 /* Library / device info: fills name (<= n bytes), returns the number of CUs via *cus. */
