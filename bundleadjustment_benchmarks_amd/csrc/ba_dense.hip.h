@@ -51,17 +51,6 @@ __device__ __forceinline__ float ba_rcp(float d)
     return r;
 }
 
-// Pinned (asm volatile) forms of the reciprocal chain: hipcc otherwise sinks the chain below the rank-1 FMAs it is
-// meant to overlap with (it is only consumed by the next loop iteration).  One instruction per statement; the s_nop
-// covers the trans-op -> VALU read hazard the compiler cannot see inside an asm.
-__device__ __forceinline__ double ba_rcp_est(double d) { double r; asm volatile("v_rcp_f64 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(d)); return r; }
-__device__ __forceinline__ float ba_rcp_est(float d) { float r; asm volatile("v_rcp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(d)); return r; }
-// 1 - d r
-__device__ __forceinline__ double ba_fnma1(double d, double r) { double e; const double one = 1.0; asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(e) : "v"(d), "v"(r), "v"(one)); return e; }
-__device__ __forceinline__ float ba_fnma1(float d, float r) { float e; const float one = 1.0f; asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(d), "v"(r), "v"(one)); return e; }
-__device__ __forceinline__ double ba_fma_(double a, double b, double c) { double r; asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float ba_fma_(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-
 #define BA_NB 64
 
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.

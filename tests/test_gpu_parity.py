@@ -164,6 +164,32 @@ def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
 
 
+@pytest.mark.parametrize("kind", [2, 1, 0])
+def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
+    """Scalar = float (src/BATypeUtils.h:6-7): one trial against the float oracle with the same elimination order.
+    fp32 leaves ~1e-3 on S (entries up to 1e9 accumulated from ~1e3 terms) and, through cond(S), a few percent on dx;
+    the energy of the trial point must agree to 1e-3."""
+    po = to_oracle(small)
+    cam = O.init_cams(po, np.float32)
+    pts = po.pts.astype(np.float32)
+    f, e = O.residuals(po, cam, pts)
+    Jc, Jp = O.jacobian(po, cam, pts)
+    s = ba.Solver(small, kind, ba.F32)
+    s.keep_intermediates(True)
+    eg, dmax = s.linearize()
+    assert abs(eg - e) < 1e-4 * e
+    okind = O.QRCHOL if kind == 0 else kind  # QRKIT on the GPU = per-point QR + LDL^T of S (DESIGN.md section 2)
+    for lam in (1.0, 100.0):
+        st = O.step(okind, po, Jc, Jp, f, lam)
+        et, rs, dn = s.try_step(lam)
+        assert relmax(s.get(ba.GET_S), st["S"]) < 5e-3
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 5e-2 * np.linalg.norm(st["dx"])
+        co, pt = O.retract(po, cam, pts, st["dx"])
+        _, e_or = O.residuals(po, co, pt)
+        assert abs(et - e_or) < 1e-3 * e_or
+
+
 def test_f32_lm_decreases(ba, gpu_ok, prob39):
     s = ba.Solver(prob39, ba.QRCHOL, ba.F32)
     r = s.minimize(max_trials=15)
