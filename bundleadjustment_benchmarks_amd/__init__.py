@@ -46,7 +46,8 @@ class Result(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("linearize_ms", C.c_double), ("eliminate_ms", C.c_double), ("schur_ms", C.c_double),
                 ("factor_ms", C.c_double), ("backsub_ms", C.c_double), ("test_eval_ms", C.c_double),
-                ("comm_ms", C.c_double), ("n_linearize", C.c_longlong), ("n_trials", C.c_longlong)]
+                ("comm_ms", C.c_double), ("trial_ms", C.c_double), ("n_linearize", C.c_longlong), ("n_trials", C.c_longlong),
+                ("n_graph_trials", C.c_longlong)]
 
 
 TRIAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double)

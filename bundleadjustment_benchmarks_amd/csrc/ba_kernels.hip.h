@@ -326,11 +326,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_vdiag(int N, cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
                                                    const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ U0,
-                                                   const T *__restrict__ gp, T lambda, T *__restrict__ rec,
+                                                   const T *__restrict__ gp, const T *__restrict__ lam, T *__restrict__ rec,
                                                    T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= K) return;
+    const T lambda = *lam;
     const int j = obs_pt[i];
     const T u0 = U0[j], u1 = U0[(size_t)Ml + j], u2 = U0[2 * (size_t)Ml + j], u3 = U0[3 * (size_t)Ml + j],
             u4 = U0[4 * (size_t)Ml + j], u5 = U0[5 * (size_t)Ml + j];
@@ -387,14 +388,14 @@ template <typename T, int LPP> __device__ __forceinline__ T group_sum(T v)
 
 template <typename T, int LPP>
 __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jc,
-                                                 const T *__restrict__ Jp, const T *__restrict__ r, T lambda, T *__restrict__ rec,
+                                                 const T *__restrict__ Jp, const T *__restrict__ r, const T *__restrict__ lam, T *__restrict__ rec,
                                                  T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
 {
     constexpr int SL = 4; // observations per lane: points with up to 4 * LPP observations
     const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
     const int j = gid < Ml ? gid : Ml - 1; // idle groups shadow the last point (no early exit: shuffles need every lane)
     const int b = pt_ptr[j], k = pt_ptr[j + 1] - b;
-    const T sl = tsqrt(lambda);
+    const T sl = tsqrt(*lam);
     T V[SL][6], Q[SL][6];
     bool ok[SL];
 #pragma unroll
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(256) void k_schur_chunks(int nchunks, const int *__
     // loop then has a single level of dependent loads (the records), two entries in flight
     const int ia_l = (sub < len) ? ent_r[e0 + sub] : 0, ib_l = (sub < len) ? ent_c[e0 + sub] : 0;
     T acc0 = 0, acc1 = 0, acc2 = 0, zacc = 0;
-#pragma unroll 2
-    for (int e = 0; e < 32; e++) {
+    const int len2 = max(len, __shfl_xor(len, 32, 64)); // the two chunks of this wavefront run in lock-step
+    for (int e = 0; e < len2; e++) {
         const int ia = __shfl(ia_l, e, 32), ib = __shfl(ib_l, e, 32);
         if (e < len && act) {
             const T *ra = rec + (size_t)ia * BA_REC;
@@ -565,8 +566,9 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld,
 // After the (optional) all-reduce: add lambda to the diagonal, copy the summed g_c out of row D+1, clear the
 // augmented rows D+1.. and give the padding a unit diagonal so that the blocked LDL^T can run over whole tiles.
 template <typename T>
-__global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, T lambda, T *__restrict__ S, T *__restrict__ gc_out)
+__global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, const T *__restrict__ lam, T *__restrict__ S, T *__restrict__ gc_out)
 {
+    const T lambda = *lam;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Dp) return;
     T *col = S + (size_t)c * ld;
@@ -586,7 +588,7 @@ template <typename T, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__ pt_ptr, const int *__restrict__ obs_cam,
                                                  const T *__restrict__ rec, const T *__restrict__ dinv, const T *__restrict__ tvec,
                                                  const T *__restrict__ tri, const T *__restrict__ dxc, const T *__restrict__ gp,
-                                                 const T *__restrict__ pts, T lambda, T *__restrict__ dxp, T *__restrict__ pts_test,
+                                                 const T *__restrict__ pts, const T *__restrict__ lam, T *__restrict__ dxp, T *__restrict__ pts_test,
                                                  T *__restrict__ partial /* [2][grid] */)
 {
     // LPP lanes per point: each lane forms Z_i^T dx_c for its observations (i = g, g + LPP, ...), a butterfly sum over
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
     s0 = group_sum<T, LPP>(s0); s1 = group_sum<T, LPP>(s1); s2 = group_sum<T, LPP>(s2);
     T rho = 0, dn = 0;
     if (gid < Ml && lg == 0) {
+        const T lambda = *lam;
         const T u0 = (tvec[j] - s0) * dinv[j], u1 = (tvec[(size_t)Ml + j] - s1) * dinv[(size_t)Ml + j],
                 u2 = (tvec[2 * (size_t)Ml + j] - s2) * dinv[2 * (size_t)Ml + j];
         const T x2 = u2 / tri[5 * (size_t)Ml + j];
@@ -630,10 +633,11 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
 // Single block (N <= a few thousand cameras); also the camera part of the rho / |dx|^2 sums -> scal[dst..dst+1].
 template <typename T>
 __global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc,
-                                                      const T *__restrict__ gc, T lambda, T *__restrict__ cam_test,
+                                                      const T *__restrict__ gc, const T *__restrict__ lam, T *__restrict__ cam_test,
                                                       T *__restrict__ scal, int dst)
 {
     __shared__ T red[4];
+    const T lambda = *lam;
     T rho = 0, dn = 0;
     for (int a = threadIdx.x; a < N; a += 256) {
         T p[9];

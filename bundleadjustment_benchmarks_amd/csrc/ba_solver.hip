@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,7 +33,7 @@ constexpr int NB = BA_NB;    // block-column width of the dense LDL^T
 constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 = spare
 constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
-       SC_ST0 = 8 /* ..11 stats */ };
+       SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */ };
 enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_N };
 
 template <typename T> struct DevBuf {
@@ -65,6 +66,7 @@ struct SolverBase {
     virtual int stats(double *out4) = 0;
     virtual int get(int what, double *out, size_t n) = 0;
     virtual int set_state(const double *cam15, const double *pts) = 0;
+    virtual void set_stream_hook() {}
     virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
     virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
     ba_allreduce_fn ar_fn = nullptr;
@@ -108,6 +110,9 @@ template <typename T> struct Solver final : SolverBase {
         d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
+    T *h_lam = nullptr;                      // pinned staging word for lambda
+    hipGraphExec_t gexec[2] = {nullptr, nullptr}; // captured trial, one per parity of the parameter double buffer
+    bool use_graph = true;
     hipEvent_t ev[EV_N] = {};
     int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
     bool have_step = false;
@@ -116,6 +121,9 @@ template <typename T> struct Solver final : SolverBase {
     {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
+        for (auto &g : gexec)
+            if (g) (void)hipGraphExecDestroy(g);
+        if (h_lam) (void)hipHostFree(h_lam);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
 
@@ -135,6 +143,8 @@ template <typename T> struct Solver final : SolverBase {
         if (kind != BA_CHOLESKY && sx.kmax > 256) return BA_ERR_ARG; // more than 256 observations of one point: not supported by k_elim_qr
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipHostMalloc((void **)&h_lam, sizeof(T)));
+        use_graph = getenv("BA_NO_GRAPH") == nullptr;
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
         UP(d_pair_lo, sx.pair_lo); UP(d_ent_r, sx.ent_r); UP(d_ent_c, sx.ent_c); UP(d_chunk_ptr, sx.chunk_ptr);
@@ -260,13 +270,13 @@ template <typename T> struct Solver final : SolverBase {
         return BA_OK;
     }
 
-    void launch_eliminate(T lambda)
+    void launch_eliminate()
     {
         if (kind == BA_CHOLESKY) {
             hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
-                               d_U0.p, d_gp.p, lambda, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+                               d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            launch_elim_qr(lambda);
+            launch_elim_qr();
         }
     }
 
@@ -274,10 +284,10 @@ template <typename T> struct Solver final : SolverBase {
     // register kernel -- ba_solver_create refuses such a problem for the QR symbols)
     int lpp() const { return sx.kmax <= 32 ? 8 : sx.kmax <= 64 ? 16 : sx.kmax <= 128 ? 32 : 64; }
 
-    void launch_elim_qr(T lambda)
+    void launch_elim_qr()
     {
 #define BA_QR(L) hipLaunchKernelGGL((k_elim_qr<T, L>), dim3(((size_t)Ml * L + 255) / 256), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jc.p, \
-                                    d_Jp.p, d_r.p, lambda, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p)
+                                    d_Jp.p, d_r.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p)
         switch (lpp()) {
         case 8: BA_QR(8); break;
         case 16: BA_QR(16); break;
@@ -346,56 +356,110 @@ template <typename T> struct Solver final : SolverBase {
         }
     }
 
-    void launch_backsub_retract(T lambda)
+    void launch_post_reduce()
+    {
+        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p);
+    }
+
+    int set_lambda(T lambda)
+    {
+        *h_lam = lambda;
+        HIPCHK(hipMemcpyAsync(d_scal.p + SC_LAMBDA, h_lam, sizeof(T), hipMemcpyHostToDevice, st));
+        return BA_OK;
+    }
+
+    void launch_backsub_retract()
     {
         hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
-                           d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, lambda, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
-        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, lambda,
+                           d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
+        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
                            d_cam[1 - cur].p, d_scal.p, (int)SC_RHO_C);
     }
 
-    // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375)
-    int try_step(double lambda_d, double *e_test, double *rho_scale, double *dx_norm) override
+    // Everything one trial enqueues after lambda has been set (single shard: no host interaction in between).
+    void launch_trial_kernels()
     {
-        const T lambda = (T)lambda_d;
-        int rc;
-        HIPCHK(hipEventRecord(ev[EV_T0], st));
-        launch_eliminate(lambda);
-        HIPCHK(hipEventRecord(ev[EV_T1], st));
+        launch_eliminate();
         launch_schur();
-        HIPCHK(hipEventRecord(ev[EV_T2], st));
-        if ((rc = allreduce(d_S.p, (size_t)ld * Dp, 0))) return rc;
-        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
-        if (keep) {
-            if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
-            HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
-        }
-        HIPCHK(hipEventRecord(ev[EV_T3], st));
+        launch_post_reduce();
         launch_factor_solve();
-        HIPCHK(hipEventRecord(ev[EV_T4], st));
-        launch_backsub_retract(lambda);
-        HIPCHK(hipEventRecord(ev[EV_T5], st));
+        launch_backsub_retract();
         launch_eval(false, 1 - cur);
         ba_red_jobs jobs{};
         jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
         jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
         jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
         hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
-        HIPCHK(hipEventRecord(ev[EV_T6], st));
-        if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
-        if ((rc = fetch_scalars())) return rc;
-        HIPCHK(hipGetLastError());
-        tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
-        tm.schur_ms += ev_ms(EV_T1, EV_T2);
-        tm.factor_ms += ev_ms(EV_T3, EV_T4);
-        tm.backsub_ms += ev_ms(EV_T4, EV_T5);
-        tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
+    }
+
+    // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375)
+    // graph = true (used by minimize on a single shard): the ~110 launches of a trial are captured once per parameter
+    // buffer parity into a hipGraph and replayed; lambda reaches the kernels through device memory.
+    int try_step_impl(double lambda_d, double *e_test, double *rho_scale, double *dx_norm, bool graph)
+    {
+        int rc;
+        if ((rc = set_lambda((T)lambda_d))) return rc;
+        if (graph && world == 1 && !keep) {
+            if (!gexec[cur]) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                launch_trial_kernels();
+                HIPCHK(hipStreamEndCapture(st, &g));
+                HIPCHK(hipGraphInstantiate(&gexec[cur], g, nullptr, nullptr, 0));
+                HIPCHK(hipGraphDestroy(g));
+            }
+            HIPCHK(hipEventRecord(ev[EV_T0], st));
+            HIPCHK(hipGraphLaunch(gexec[cur], st));
+            HIPCHK(hipEventRecord(ev[EV_T6], st));
+            if ((rc = fetch_scalars())) return rc;
+            HIPCHK(hipGetLastError());
+            tm.trial_ms += ev_ms(EV_T0, EV_T6);
+            tm.n_graph_trials++;
+        } else {
+            HIPCHK(hipEventRecord(ev[EV_T0], st));
+            launch_eliminate();
+            HIPCHK(hipEventRecord(ev[EV_T1], st));
+            launch_schur();
+            HIPCHK(hipEventRecord(ev[EV_T2], st));
+            if ((rc = allreduce(d_S.p, (size_t)ld * Dp, 0))) return rc;
+            launch_post_reduce();
+            if (keep) {
+                if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
+                HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
+            }
+            HIPCHK(hipEventRecord(ev[EV_T3], st));
+            launch_factor_solve();
+            HIPCHK(hipEventRecord(ev[EV_T4], st));
+            launch_backsub_retract();
+            HIPCHK(hipEventRecord(ev[EV_T5], st));
+            launch_eval(false, 1 - cur);
+            ba_red_jobs jobs{};
+            jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
+            jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
+            jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
+            hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
+            HIPCHK(hipEventRecord(ev[EV_T6], st));
+            if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
+            if ((rc = fetch_scalars())) return rc;
+            HIPCHK(hipGetLastError());
+            tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
+            tm.schur_ms += ev_ms(EV_T1, EV_T2);
+            tm.factor_ms += ev_ms(EV_T3, EV_T4);
+            tm.backsub_ms += ev_ms(EV_T4, EV_T5);
+            tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
+            tm.trial_ms += ev_ms(EV_T0, EV_T6);
+        }
         tm.n_trials++;
         if (e_test) *e_test = (double)h_scal[SC_ETEST];
         if (rho_scale) *rho_scale = (double)(h_scal[SC_RHO_P] + h_scal[SC_RHO_C]);
         if (dx_norm) *dx_norm = std::sqrt((double)(h_scal[SC_DN_P] + h_scal[SC_DN_C]));
         have_step = true;
         return BA_OK;
+    }
+
+    int try_step(double lambda_d, double *e_test, double *rho_scale, double *dx_norm) override
+    {
+        return try_step_impl(lambda_d, e_test, rho_scale, dx_norm, false);
     }
 
     int accept() override
@@ -560,7 +624,7 @@ template <typename T> struct Solver final : SolverBase {
                 if (lm.max_trials > 0 && trials >= lm.max_trials) { stop = true; status = BA_RUNNING; break; }
                 const auto t0 = std::chrono::steady_clock::now();
                 double et = 0, rs = 0, dn = 0;
-                if ((rc = try_step((double)lambda, &et, &rs, &dn))) { stop = true; break; }
+                if ((rc = try_step_impl((double)lambda, &et, &rs, &dn, use_graph))) { stop = true; break; }
                 fun_evals++;
                 const T e_test = (T)et;
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -600,8 +664,11 @@ template <typename T> struct Solver final : SolverBase {
             out->energy = (double)energy; out->lambda = (double)lambda;
             out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tbeg).count();
             const long long nt = tm.n_trials - tm0.n_trials, nl = tm.n_linearize - tm0.n_linearize;
-            out->schur_ms = nt ? ((tm.eliminate_ms - tm0.eliminate_ms) + (tm.schur_ms - tm0.schur_ms) + (tm.factor_ms - tm0.factor_ms) +
-                                  (tm.backsub_ms - tm0.backsub_ms)) / nt : 0.0;
+            const long long ng = tm.n_graph_trials - tm0.n_graph_trials;
+            // graph replay: only the whole trial is timed (it includes the ~20 us test-energy evaluation)
+            out->schur_ms = !nt ? 0.0 : ng == nt ? (tm.trial_ms - tm0.trial_ms) / nt
+                                : ((tm.eliminate_ms - tm0.eliminate_ms) + (tm.schur_ms - tm0.schur_ms) + (tm.factor_ms - tm0.factor_ms) +
+                                   (tm.backsub_ms - tm0.backsub_ms)) / (nt - ng > 0 ? nt - ng : 1);
             out->linearize_ms = nl ? (tm.linearize_ms - tm0.linearize_ms) / nl : 0.0;
         }
         return rc;
@@ -610,26 +677,27 @@ template <typename T> struct Solver final : SolverBase {
     int time_phase(int phase, int reps, double lambda_d, double *ms) override
     {
         if (reps < 1 || !ms) return BA_ERR_ARG;
-        const T lambda = (T)lambda_d;
         double acc_ms = 0;
+        int rcl = set_lambda((T)lambda_d);
+        if (rcl) return rcl;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipEventRecord(ev[EV_T0], st));
         for (int k = 0; k < reps; k++) {
             switch (phase) {
             case 0: launch_eval(false, cur); break;
             case 1: launch_eval(true, cur); launch_grad(); break;
-            case 2: launch_eliminate(lambda); break;
+            case 2: launch_eliminate(); break;
             case 3: launch_schur(); break;
             case 4:
                 launch_schur(); // the factorisation is in place: rebuild S first (timed separately by phase 3)
-                hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
+                launch_post_reduce();
                 launch_factor_solve();
                 break;
-            case 5: launch_backsub_retract(lambda); break;
+            case 5: launch_backsub_retract(); break;
             case 6: // dense factorisation only (k_ldlt_panel + k_ldlt_step / k_ldlt_update): events around it, per rep
             case 7: // backward sweep only (k_ldlt_backstep)
                 launch_schur();
-                hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, lambda, d_S.p, d_gcg.p);
+                launch_post_reduce();
                 if (phase == 6) HIPCHK(hipEventRecord(ev[EV_T2], st));
                 launch_factor();
                 if (phase == 6) HIPCHK(hipEventRecord(ev[EV_T3], st));

@@ -175,7 +175,8 @@ typedef struct {
     double backsub_ms;    /* point back-substitution + retraction */
     double test_eval_ms;  /* residual at xTest + scalar reductions */
     double comm_ms;       /* host wall time spent inside the all-reduce callback */
-    long long n_linearize, n_trials;
+    double trial_ms;      /* whole trial, device time (the only per-trial figure when the trial is replayed as a hipGraph) */
+    long long n_linearize, n_trials, n_graph_trials;
 } ba_timing;
 int ba_solver_timing(ba_solver *s, ba_timing *out, int reset);
 
