@@ -125,8 +125,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
     __shared__ T Wl[NB][NB + 1]; // W[row][col]
-    __shared__ T Ys[16][NB + 1]; // unscaled sub-panel Y[col][row]
-    __shared__ T Ts[3][16][17];  // per-wave scratch of the W assembly
+    // Ys (unscaled sub-panel Y[col][row], live in the A2 / A3 phases) and Ts (per-wave scratch of the W tiles, live in
+    // the A1 phases and after the loop) are never live together: they share storage, which keeps the workgroup under
+    // 80 KiB so that two workgroups fit a CU (the trailing-update workgroups of the fused launch inherit the footprint).
+    __shared__ T YsTs[16 * (NB + 1)];
+    T (*Ys)[NB + 1] = reinterpret_cast<T (*)[NB + 1]>(YsTs);
+    T (*Ts)[16][17] = reinterpret_cast<T (*)[16][17]>(YsTs);
+    static_assert(3 * 16 * 17 <= 16 * (NB + 1), "Ts must fit into Ys");
     __shared__ T colx4[4][16], wtile[16][17], dinv[NB], junkbuf[64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);

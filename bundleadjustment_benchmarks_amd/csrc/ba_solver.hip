@@ -321,7 +321,7 @@ template <typename T> struct Solver final : SolverBase {
             T *wcur = d_Wp.p + (size_t)(p & 1) * wsz, *wprev = d_Wp.p + (size_t)((p + 1) & 1) * wsz;
             // Look-ahead pays once the trailing update is big enough to be worth hiding (measured: D >= ~2000); for small
             // matrices the panel's extra update work costs more than the saved launch.
-            const bool fused = nblk >= 24 && nblk <= 72; // beyond ~4600 the update needs the occupancy the panel's LDS footprint denies it
+            const bool fused = nblk >= 24;
             if (p == 0 || !fused) {
                 hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
                                    fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB);
@@ -335,7 +335,11 @@ template <typename T> struct Solver final : SolverBase {
                 const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                hipLaunchKernelGGL((k_ldlt_step<T, NB>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, d_S.p,
+                // Up to D ~ 3000 the panel is the critical path: an unused dynamic-LDS request keeps the launch at one
+                // workgroup per CU so that a panel workgroup never shares its CU with an update workgroup; beyond, the
+                // update dominates and two workgroups per CU (the static footprint is < 80 KiB) are faster.
+                const unsigned pad = nblk < 48 ? 8192u : 0u;
+                hipLaunchKernelGGL((k_ldlt_step<T, NB>), dim3(npanel + nupd), dim3(256), pad, st, nrows, ncols, ld, p0, npanel, d_S.p,
                                    wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
             }
         }
