@@ -101,6 +101,11 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
 template <typename T, int NB, bool TOLDS>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1]);
+template <typename T, int NB, bool TOLDS>
+__device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad);
+template <typename T, int NB>
+__device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, int row0t, int col0t, T *S, const T *Wp, int quad);
 
 // Panel step for block column p0: rows [p0, nrows), pivots [p0, min(p0 + 64, ncols)).
 //   S    : in place; on exit the block column holds L (strictly lower) and D (diagonal)
@@ -118,7 +123,7 @@ __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int co
 //   A3  the remaining tiles of the block get the rank-16 update on the matrix cores.
 // W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
 // block need Y = A21 W^T -- a GEMM, also on the matrix cores.
-template <typename T, int NB>
+template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                               T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel)
 {
@@ -148,10 +153,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         // workgroups, except for block column p0 itself, which this step needs now: every panel workgroup applies it to
         // the diagonal block (in LDS, redundantly) and to its own 64 rows below (in S).
         ba_update_tile<T, NB, true>(ld, p0 - NB, p0, p0, true, S, Wprev, Ad);
-        const int rown = p0 + NB + 64 * blk;
-        if (rown < nrows) ba_update_tile<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr);
-        __syncthreads(); // (s_waitcnt vmcnt(0) + barrier: the S stores above are complete; phase B reads them past L1)
+        __syncthreads();
+        // the update of this workgroup's own 64 rows below is only needed by the GEMM at the very end: waves 1..3 do it
+        // while wave 0 factors the first two sub-panels (see the A1 stage); every later barrier waits for the stores
+        // (s_waitcnt vmcnt(0)), and the GEMM reads them past L1
     }
+    const int rown = p0 + NB + 64 * blk;
+    const bool own_rows = Wprev != nullptr && rown < nrows;
     typedef typename ba_acc<T>::type acc_t;
     BA_STAMP_DECL
     BA_STAMP_GET(st_t0);
@@ -246,8 +254,16 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #ifdef BA_STAMP2
             if (blk == 0 && lane == 0) for (int q2 = 0; q2 < 4; q2++) ba_stamp_acc[32 + 4 * s + q2] = st2_acc[q2];
 #endif
-        } else if (s >= 2 && wv - 1 < s - 1) {
-            w_tile(s - 1, wv - 1, wv - 1); // row s-1 of W, block column wv-1, while wave 0 factors sub-panel s
+        } else {
+            if (own_rows) { // look-ahead update of the rows below, hidden under A1(0) (quadrants 0..2) and A1(1) (quadrant 3)
+                // INL: inlined (fastest, but ~250 VGPRs: one workgroup per CU) or out of line (116 VGPRs: two per CU)
+                const int quad = (s == 0) ? wv - 1 : (s == 1 && wv == 1) ? 3 : -1;
+                if (quad >= 0) {
+                    if (INL) ba_update_quad<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, quad);
+                    else ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, quad);
+                }
+            }
+            if (s >= 2 && wv - 1 < s - 1) w_tile(s - 1, wv - 1, wv - 1); // row s-1 of W, block column wv-1
         }
         __syncthreads();
         BA_STAMP_SEG(0);
@@ -360,7 +376,7 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                                     T *__restrict__ Winv)
 {
-    ba_panel_body<T, NB>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x);
+    ba_panel_body<T, NB, false>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x);
 }
 
 // Fused step with look-ahead: ONE launch per block column p0 >= 64.
@@ -368,12 +384,12 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 //   workgroups [npanel, gridDim.x): the rest of the trailing update of block column p0 - 64 (tiles with columns >= p0 + 64).
 // The two groups touch disjoint parts of S; Wp is double-buffered (Wprev read, Wp written).  The panel's 2313-long pivot
 // recurrence is the critical path of the factorisation; this hides the MFMA update behind it.
-template <typename T, int NB>
+template <typename T, int NB, bool INL>
 __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
                                                    T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv)
 {
     if ((int)blockIdx.x < npanel) {
-        ba_panel_body<T, NB>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, blockIdx.x, npanel);
+        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, blockIdx.x, npanel);
         return;
     }
     // tile u of the set {(ti, tj): 1 <= tj <= ti, tj < ntc}, rows p0 + 64 ti, columns p0 + 64 tj
@@ -398,11 +414,11 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
 // flight at once to cover the L2 latency.  LOWER: skip the strictly upper quadrant (diagonal tiles).
 // TOLDS: the C tile lives in the LDS image Cl[col][row] (64 x 65) instead of S (diagonal block inside the panel step).
 template <typename T, int NB, bool TOLDS>
-__device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1])
+__device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad)
 {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int qr = 32 * (w >> 1), qc = 32 * (w & 1);
+    const int lane = threadIdx.x & 63;
+    const int qr = 32 * (quad >> 1), qc = 32 * (quad & 1);
     if (lower && qc > qr) return;
     const int row0 = row0t + qr, col0 = col0t + qc;
     const int li = lane & 15, lk = lane >> 4;
@@ -445,6 +461,21 @@ __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int co
                 if (TOLDS) Cl[qc + cc][qr + rr] = acc[t][u][v];
                 else S[(size_t)(col0 + cc) * ld + row0 + rr] = acc[t][u][v];
             }
+}
+
+template <typename T, int NB, bool TOLDS>
+__device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1])
+{
+    ba_update_quad<T, NB, TOLDS>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6); // wave w owns quadrant w
+}
+
+// Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
+// registers are merged into the allocation of the fully unrolled pivot loop (251 VGPRs instead of 95).
+template <typename T, int NB>
+__device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, int row0t, int col0t, T *S, const T *Wp, int quad)
+{
+    ba_update_quad<T, NB, false>(ld, p0, row0t, col0t, false, S, Wp, nullptr, quad);
 }
 
 // Stand-alone trailing update (one launch per block column; kept for the non-fused path and the dense bench).

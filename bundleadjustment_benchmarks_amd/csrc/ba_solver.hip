@@ -335,11 +335,14 @@ template <typename T> struct Solver final : SolverBase {
                 const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                // Up to D ~ 3000 the panel is the critical path: an unused dynamic-LDS request keeps the launch at one
-                // workgroup per CU so that a panel workgroup never shares its CU with an update workgroup; beyond, the
-                // update dominates and two workgroups per CU (the static footprint is < 80 KiB) are faster.
-                const unsigned pad = nblk < 48 ? 8192u : 0u;
-                hipLaunchKernelGGL((k_ldlt_step<T, NB>), dim3(npanel + nupd), dim3(256), pad, st, nrows, ncols, ld, p0, npanel, d_S.p,
+                // Up to D ~ 3000 the panel is the critical path: the variant with the look-ahead update inlined into the
+                // sub-panel loop (~250 VGPRs, one workgroup per CU, so a panel workgroup never shares its CU with an update
+                // workgroup).  Beyond, the update dominates: out-of-line variant, 116 VGPRs + < 80 KiB LDS = two per CU.
+                if (nblk < 48)
+                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(npanel + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, npanel, d_S.p,
+                                       wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
+                else
+                    hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, d_S.p,
                                    wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
             }
         }

@@ -59,7 +59,7 @@ int main(int argc, char **argv)
                 const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                hipLaunchKernelGGL((k_ldlt_step<double, NB>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+                if (nblk < 48) hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB); else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
             }
         }
         CK(hipEventRecord(e1, st));
