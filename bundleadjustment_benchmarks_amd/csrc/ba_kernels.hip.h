@@ -56,7 +56,8 @@ template <typename T, bool JAC>
 __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__restrict__ cam, const T *__restrict__ pts,
                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                                               const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
-                                              T *__restrict__ Jp, T *__restrict__ partial)
+                                              T *__restrict__ Jp, T *__restrict__ JcA /* [K][20] AoS copy: A (18), r (2) */,
+                                              T *__restrict__ partial)
 {
     __shared__ T red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -88,6 +89,8 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
         if (JAC) {
             r[i] = e0;
             r[(size_t)K + i] = e1;
+            JcA[(size_t)i * 20 + 18] = e0;
+            JcA[(size_t)i * 20 + 19] = e1;
             // -[XX - T]x  (poseDerivatives, BAFunctor.h:131-133; XX - T is formed as the reference forms it)
             const T v0 = XX0 - c[9], v1 = XX1 - c[10], v2 = XX2 - c[11];
             const T mJ[9] = {0, v2, -v1, -v2, 0, v0, v1, -v0, 0};
@@ -129,6 +132,8 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
                 if (q < 9) {
                     Jc[(size_t)q * K + i] = t0;
                     Jc[(size_t)(9 + q) * K + i] = t1;
+                    JcA[(size_t)i * 20 + q] = t0; // gathered by camera in k_cam_gram: one 160-byte record per observation
+                    JcA[(size_t)i * 20 + 9 + q] = t1;
                 } else {
                     Jp[(size_t)(q - 9) * K + i] = t0;
                     Jp[(size_t)(q - 6) * K + i] = t1;
@@ -244,8 +249,8 @@ __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__
 // latency-bound (85 us for 226 k observations).
 template <typename T>
 __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
-                                                  const int *__restrict__ cam_obs, const T *__restrict__ Jc,
-                                                  const T *__restrict__ r, T *__restrict__ dslab)
+                                                  const int *__restrict__ cam_obs, const T *__restrict__ JcA,
+                                                  T *__restrict__ dslab)
 {
     __shared__ T xch[8][27][33];
     const int gl = threadIdx.x >> 5, g = blockIdx.x * 8 + gl, sub = threadIdx.x & 31;
@@ -255,11 +260,11 @@ __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int
 #pragma unroll
     for (int q = 0; q < 54; q++) v[q] = 0;
     if (sub < len) {
-        const int i = cam_obs[e0 + sub];
+        const T *rec = JcA + (size_t)cam_obs[e0 + sub] * 20;
         T a0[9], a1[9];
 #pragma unroll
-        for (int c = 0; c < 9; c++) { a0[c] = Jc[(size_t)c * K + i]; a1[c] = Jc[(size_t)(9 + c) * K + i]; }
-        const T r0 = r[i], r1 = r[(size_t)K + i];
+        for (int c = 0; c < 9; c++) { a0[c] = rec[c]; a1[c] = rec[9 + c]; }
+        const T r0 = rec[18], r1 = rec[19];
         int q = 0;
 #pragma unroll
         for (int c = 0; c < 9; c++)

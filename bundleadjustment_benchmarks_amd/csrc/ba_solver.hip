@@ -106,7 +106,7 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
     // state and work arrays
-    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
+    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
         d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
@@ -176,7 +176,7 @@ template <typename T> struct Solver final : SolverBase {
             return rc;
         const size_t K1 = Kl > 0 ? Kl : 1, M1 = Ml > 0 ? Ml : 1;
 #define AL(buf, n) if ((rc = buf.alloc(n))) return rc
-        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
+        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
         AL(d_gc, (size_t)D); AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
@@ -221,10 +221,10 @@ template <typename T> struct Solver final : SolverBase {
         const T tau2 = tau * tau;
         if (jac)
             hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_part_e.p);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p);
         else
             hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p);
     }
 
     void launch_grad()
@@ -233,7 +233,7 @@ template <typename T> struct Solver final : SolverBase {
                            d_part_pm.p);
         if (sx.ndchunks > 0)
             hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
-                               d_dchunk_ptr.p, d_cam_obs.p, d_Jc.p, d_r.p, d_dslab.p);
+                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p);
         hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
                            d_dslab.p, d_V.p, d_gc.p);
     }
