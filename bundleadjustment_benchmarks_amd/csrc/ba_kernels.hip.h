@@ -586,6 +586,23 @@ __global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, cons
     }
 }
 
+// ---- multi-GPU: pack / unpack the block-lower trapezoid of S around the all-reduce ----------------------------------
+// Only rows >= 64 (c / 64) of column c carry data (lower triangle + the augmented rows D, D+1 at the bottom); packing
+// them into one contiguous buffer halves the bytes every rank sends over xGMI.  off[p] = start of block column p.
+template <typename T, bool UNPACK>
+__global__ __launch_bounds__(256) void k_pack_lower(int Dp, int ld, T *__restrict__ S, T *__restrict__ buf)
+{
+    const int c = blockIdx.y;                 // column
+    const int p = c >> 6, r0 = p << 6;        // block column, first kept row
+    const int h = Dp - r0;                    // kept rows of this column
+    // offset of block column p: sum_{q<p} 64 (Dp - 64 q) ; plus the columns before c inside the block
+    const size_t off = (size_t)64 * ((size_t)p * Dp - (size_t)32 * p * (p - 1)) + (size_t)(c - r0) * h;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < h; r += gridDim.x * 256) {
+        if (UNPACK) S[(size_t)c * ld + r0 + r] = buf[off + r];
+        else buf[off + r] = S[(size_t)c * ld + r0 + r];
+    }
+}
+
 // ---- K7 + K8 (points): back-substitution, point retraction, rho terms ----------------------------------------
 // dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i]))  (src/Eigen_ext/BacktrackLevMarqQRChol.h:343-360);
 // x_test = x + dx_p (src/Optimization/BAFunctor.h:335-338); partial sums of dx^T (lambda dx + JtRes) (:375) and |dx|^2.

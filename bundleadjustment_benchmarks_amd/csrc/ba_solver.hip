@@ -107,7 +107,7 @@ template <typename T> struct Solver final : SolverBase {
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
     // state and work arrays
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
-        d_slab, d_S, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
+        d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
     T *h_lam = nullptr;                      // pinned staging word for lambda
@@ -428,7 +428,16 @@ template <typename T> struct Solver final : SolverBase {
             HIPCHK(hipEventRecord(ev[EV_T1], st));
             launch_schur();
             HIPCHK(hipEventRecord(ev[EV_T2], st));
-            if ((rc = allreduce(d_S.p, (size_t)ld * Dp, 0))) return rc;
+            if (world > 1) {
+                // all-reduce only the block-lower trapezoid (matrix + rhs row + g_c row): half the bytes of the full buffer
+                const int nbc = Dp / NB;
+                const size_t npk = (size_t)64 * ((size_t)nbc * Dp - (size_t)32 * nbc * (nbc - 1));
+                if (!d_pack.p && (rc = d_pack.alloc(npk))) return rc;
+                const dim3 gpk((Dp + 255) / 256 > 8 ? 8 : (Dp + 255) / 256, Dp);
+                hipLaunchKernelGGL((k_pack_lower<T, false>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p);
+                if ((rc = allreduce(d_pack.p, npk, 0))) return rc;
+                hipLaunchKernelGGL((k_pack_lower<T, true>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p);
+            }
             launch_post_reduce();
             if (keep) {
                 if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
