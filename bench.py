@@ -84,6 +84,10 @@ def cpu_baseline(name, prob, budget_s=20.0):
     import numpy as np
     import oracle_lib as O
     kind, scalar, _, _, _ = WORKLOADS[name]
+    if 9 * prob.N > 4000:
+        # one oracle trial costs D^3/3 flops in plain C (minutes at D = 9216): outside the 10-30 s budget of this leg
+        return {"value": None, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                "sample": "skipped: a single oracle trial at D = %d exceeds the CPU budget; see the cfg4 line" % (9 * prob.N)}
     a = prob.arrays()
     po = O.Problem(prob.N, prob.M, prob.K, a["cam_idx"], a["pt_idx"], a["meas"], a["cams9"], a["pts"])
     dt = np.float64 if scalar == "f64" else np.float32
