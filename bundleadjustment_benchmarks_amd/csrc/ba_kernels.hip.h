@@ -631,7 +631,12 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
     }
     s0 = group_sum<T, LPP>(s0); s1 = group_sum<T, LPP>(s1); s2 = group_sum<T, LPP>(s2);
     T rho = 0, dn = 0;
-    if (gid < Ml && lg == 0) {
+    if (gid < Ml && lg == 0 && b == e) {
+        // a point without observations: its block of J'J + lambda I is lambda I with a zero gradient -> no step
+        // (the per-observation elimination kernel never visits it, so its factors are not even written)
+        dxp[j] = 0; dxp[(size_t)Ml + j] = 0; dxp[2 * (size_t)Ml + j] = 0;
+        pts_test[j] = pts[j]; pts_test[(size_t)Ml + j] = pts[(size_t)Ml + j]; pts_test[2 * (size_t)Ml + j] = pts[2 * (size_t)Ml + j];
+    } else if (gid < Ml && lg == 0) {
         const T lambda = *lam;
         const T u0 = (tvec[j] - s0) * dinv[j], u1 = (tvec[(size_t)Ml + j] - s1) * dinv[(size_t)Ml + j],
                 u2 = (tvec[2 * (size_t)Ml + j] - s2) * dinv[2 * (size_t)Ml + j];

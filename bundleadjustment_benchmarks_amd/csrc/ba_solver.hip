@@ -188,6 +188,9 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipMemset(d_Wp.p, 0, sizeof(T) * d_Wp.n));
         HIPCHK(hipMemset(d_scal.p, 0, sizeof(T) * NSCAL));
         HIPCHK(hipMemset(d_dxc.p, 0, sizeof(T) * d_dxc.n));
+        HIPCHK(hipMemset(d_part_bs.p, 0, sizeof(T) * d_part_bs.n));
+        HIPCHK(hipMemset(d_part_e.p, 0, sizeof(T) * d_part_e.n));
+        HIPCHK(hipMemset(d_part_pm.p, 0, sizeof(T) * d_part_pm.n));
         HIPCHK(hipDeviceSynchronize());
         return BA_OK;
     }
@@ -288,6 +291,7 @@ template <typename T> struct Solver final : SolverBase {
     {
 #define BA_QR(L) hipLaunchKernelGGL((k_elim_qr<T, L>), dim3(((size_t)Ml * L + 255) / 256), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jc.p, \
                                     d_Jp.p, d_r.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p)
+        if (Ml <= 0) return; // an empty shard owns no points
         switch (lpp()) {
         case 8: BA_QR(8); break;
         case 16: BA_QR(16); break;
@@ -377,6 +381,7 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_backsub_retract()
     {
+        if (Ml > 0) // (an empty shard keeps the zero partial sums written at creation)
         hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
                            d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
         hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,

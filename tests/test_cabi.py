@@ -142,3 +142,11 @@ def test_executables_keep_reference_cli(exe):
     assert r.returncode == 1 and "Usage:" in r.stderr and "<sparse reconstruction file>" in r.stderr
     r = subprocess.run([path, "/nonexistent/file.txt"], capture_output=True, text=True)
     assert r.returncode == 2 and r.stderr.strip() == "Cannot open /nonexistent/file.txt"
+
+
+def test_shard_plan_with_more_ranks_than_points(ba):
+    p = ba.Problem.synthetic(3, 5, 12, 2)
+    plans = [p.shard_plan(r, 8) for r in range(8)]
+    assert plans[0]["p0"] == 0 and plans[-1]["p1"] == 5
+    assert sum(q["o1"] - q["o0"] for q in plans) == 12 and sum(q["p1"] - q["p0"] for q in plans) == 5
+    assert any(q["p1"] == q["p0"] for q in plans)  # some shards are empty: allowed

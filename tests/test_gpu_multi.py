@@ -99,3 +99,18 @@ def test_rccl_allreduce_on_raw_device_pointer(ba, gpu_ok):
         assert x[10:15].tolist() == [11.0, 12.0, 13.0, 14.0, 15.0]
     finally:
         dist.destroy_process_group()
+
+
+def test_empty_shard_does_not_fault(ba, gpu_ok):
+    """More ranks than points: a shard that owns nothing must still walk through a trial (its partial sums are zero)."""
+    p = ba.Problem.synthetic(3, 5, 12, 2)
+    plans = [p.shard_plan(r, 8) for r in range(8)]
+    empty = [r for r, q in enumerate(plans) if q["p1"] == q["p0"]]
+    assert empty
+    for kind in (ba.CHOLESKY, ba.QRCHOL):
+        s = ba.Solver(p, kind, ba.F64, shard_rank=empty[0], shard_world=8)
+        s.set_allreduce(lambda ptr, count, scalar, op, stream: 0)  # stands in for the sum over the other (absent) ranks
+        e, _ = s.linearize()
+        assert e == 0.0
+        et, rs, dn = s.try_step(1.0)
+        assert et == 0.0 and np.isfinite(rs) and np.isfinite(dn)

@@ -196,3 +196,65 @@ def test_f32_lm_decreases(ba, gpu_ok, prob39):
     acc = r["trace"][r["trace"][:, 1] == 1]
     assert len(acc) >= 3
     assert np.all(np.diff(acc[:, 2]) < 0)
+
+
+def _ragged_problem(ba):
+    """Ragged input: points with a single observation, a point and a camera with none, unsorted observation order."""
+    p = ba.Problem.synthetic(9, 260, 900, 31)
+    a = p.arrays()
+    keep = np.ones(p.K, bool)
+    pt = a["pt_idx"]
+    for j in (3, 40, 41, 200):            # keep only the first observation of these points
+        idx = np.where(pt == j)[0]
+        keep[idx[1:]] = False
+    keep[pt == 77] = False               # point 77 loses all its observations
+    keep[a["cam_idx"] == 5] = False      # camera 5 sees nothing
+    perm = np.random.default_rng(1).permutation(int(keep.sum()))  # and the file is not sorted by point
+    cam_idx, pt_idx = a["cam_idx"][keep][perm], pt[keep][perm]
+    meas = a["meas"].reshape(-1, 2)[keep][perm].ravel()
+    return ba.Problem.from_arrays(p.N, p.M, int(keep.sum()), cam_idx, pt_idx, meas, a["cams9"], a["pts"])
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+def test_ragged_and_unsorted_input(ba, O, gpu_ok, kind):
+    p = _ragged_problem(ba)
+    a = p.arrays()
+    order = np.argsort(a["pt_idx"], kind="stable")  # the library sorts stably by point; the oracle needs sorted input
+    po = O.Problem(p.N, p.M, p.K, a["cam_idx"][order], a["pt_idx"][order], a["meas"].reshape(-1, 2)[order].ravel(), a["cams9"], a["pts"])
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(p, kind, ba.F64)
+    s.keep_intermediates(True)
+    eg, dmax = s.linearize()
+    assert abs(eg - e) < 1e-12 * e
+    assert relmax(s.get(ba.GET_RESIDUALS), f) < 1e-11       # residuals come back in point-sorted order
+    for lam in (1e-3, 5.0):
+        st = O.step(kind, po, Jc, Jp, f, lam)
+        et, rs, dn = s.try_step(lam)
+        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
+        assert np.all(dx[3 * 77: 3 * 77 + 3] == 0)          # the unobserved point does not move
+        blk = s.get(ba.GET_S)[45:54, 45:54]
+        assert np.allclose(blk, lam * np.eye(9), rtol=0, atol=1e-300)  # the blind camera's block is lambda I
+    r = s.minimize(max_trials=10)
+    acc = r["trace"][r["trace"][:, 1] == 1]
+    assert len(acc) >= 3 and np.all(np.diff(acc[:, 2]) < 0)
+
+
+def test_tiny_problem_and_minimal_sizes(ba, O, gpu_ok):
+    """Smallest shapes: 2 cameras, 2 points, 4 observations; D = 18 < one LDL^T block column."""
+    p = ba.Problem.synthetic(2, 2, 4, 5)
+    po = to_oracle(p)
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    for kind in (2, 1):
+        s = ba.Solver(p, kind, ba.F64)
+        eg, _ = s.linearize()
+        assert abs(eg - e) <= 1e-12 * max(e, 1e-300)
+        st = O.step(kind, po, Jc, Jp, f, 0.5)
+        s.try_step(0.5)
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-9 * max(np.linalg.norm(st["dx"]), 1e-300)
