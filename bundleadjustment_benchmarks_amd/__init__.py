@@ -27,7 +27,7 @@ EXPORTS = [
     "ba_solver_create", "ba_solver_free", "ba_solver_set_allreduce", "ba_solver_set_stream", "ba_solver_shard",
     "ba_minimize", "ba_solver_linearize", "ba_solver_try_step", "ba_solver_accept", "ba_solver_stats", "ba_solver_get",
     "ba_solver_keep_intermediates", "ba_solver_set_state", "ba_solver_timing", "ba_solver_time_phase", "ba_device_info",
-    "ba_version", "ba_shard_plan",
+    "ba_version", "ba_shard_plan", "ba_problem_save_cache", "ba_problem_load_cache",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
         L.ba_problem_create.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.ba_device_info.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ba_shard_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ba_problem_save_cache.argtypes = [C.c_void_p, C.c_char_p]
+        L.ba_problem_load_cache.argtypes = [C.c_char_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -177,6 +179,15 @@ class Problem:
         _chk(lib().ba_shard_plan(self._h, rank, world, out), "ba_shard_plan")
         keys = ("p0", "p1", "o0", "o1", "entries", "chunks", "pairs", "was_sorted")
         return dict(zip(keys, [int(v) for v in out]))
+
+    @classmethod
+    def load_cache(cls, path):
+        h = C.c_void_p()
+        _chk(lib().ba_problem_load_cache(str(path).encode(), C.byref(h)), "ba_problem_load_cache(%s)" % path)
+        return cls(h)
+
+    def save_cache(self, path):
+        _chk(lib().ba_problem_save_cache(self._h, str(path).encode()), "ba_problem_save_cache")
 
     def save_bal(self, path):
         _chk(lib().ba_problem_save_bal(self._h, str(path).encode()), "ba_problem_save_bal")

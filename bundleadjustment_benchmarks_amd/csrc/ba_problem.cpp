@@ -149,6 +149,52 @@ int ba_problem_save_bal(const ba_problem *p, const char *path)
     return BA_OK;
 }
 
+static const char BA_CACHE_MAGIC[8] = {'B', 'A', 'L', 'c', 'a', 'c', 'h', '1'};
+
+int ba_problem_save_cache(const ba_problem *p, const char *path)
+{
+    if (!p || !path) return BA_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return BA_ERR_FILE;
+    const long long hdr[3] = {p->N, p->M, p->K};
+    bool ok = fwrite(BA_CACHE_MAGIC, 1, 8, f) == 8 && fwrite(hdr, sizeof(long long), 3, f) == 3;
+    ok = ok && fwrite(p->cam_idx.data(), sizeof(int), p->K, f) == (size_t)p->K && fwrite(p->pt_idx.data(), sizeof(int), p->K, f) == (size_t)p->K;
+    ok = ok && fwrite(p->meas.data(), sizeof(double), p->meas.size(), f) == p->meas.size();
+    ok = ok && fwrite(p->cams9.data(), sizeof(double), p->cams9.size(), f) == p->cams9.size();
+    ok = ok && fwrite(p->pts.data(), sizeof(double), p->pts.size(), f) == p->pts.size();
+    fclose(f);
+    return ok ? BA_OK : BA_ERR_FILE;
+}
+
+int ba_problem_load_cache(const char *path, ba_problem **out)
+{
+    if (!path || !out) return BA_ERR_ARG;
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return BA_ERR_FILE;
+    char magic[8];
+    long long hdr[3];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, BA_CACHE_MAGIC, 8) != 0 || fread(hdr, sizeof(long long), 3, f) != 3 || hdr[0] <= 0 ||
+        hdr[1] <= 0 || hdr[2] <= 0 || hdr[0] > (1 << 24) || hdr[1] > (1LL << 30) || hdr[2] > (1LL << 30)) {
+        fclose(f);
+        return BA_ERR_PARSE;
+    }
+    ba_problem *p = new (std::nothrow) ba_problem;
+    if (!p) { fclose(f); return BA_ERR_NOMEM; }
+    p->N = (int)hdr[0]; p->M = (int)hdr[1]; p->K = (int)hdr[2];
+    p->cam_idx.resize(p->K); p->pt_idx.resize(p->K); p->meas.resize(2 * (size_t)p->K);
+    p->cams9.resize(9 * (size_t)p->N); p->pts.resize(3 * (size_t)p->M);
+    bool ok = fread(p->cam_idx.data(), sizeof(int), p->K, f) == (size_t)p->K && fread(p->pt_idx.data(), sizeof(int), p->K, f) == (size_t)p->K;
+    ok = ok && fread(p->meas.data(), sizeof(double), p->meas.size(), f) == p->meas.size();
+    ok = ok && fread(p->cams9.data(), sizeof(double), p->cams9.size(), f) == p->cams9.size();
+    ok = ok && fread(p->pts.data(), sizeof(double), p->pts.size(), f) == p->pts.size();
+    ok = ok && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok || validate(p) != BA_OK) { delete p; return BA_ERR_PARSE; }
+    *out = p;
+    return BA_OK;
+}
+
 // ---- synthetic generator --------------------------------------------------------------------------------
 // Cameras on a ring of radius 10 looking at the origin, BAL sign convention (P = R X + T, scene at negative camera z,
 // K00 = -f).  std::mt19937_64's output sequence is fixed by the C++ standard; the distributions are written out here

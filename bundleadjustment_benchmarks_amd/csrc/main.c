@@ -3,7 +3,8 @@
  * (`<exe> <sparse reconstruction file>`), exit codes (:26-31), stdout protocol (:61-171) and one executable per
  * solver symbol (-DQRKIT / -DQRCHOL / -DCHOLESKY, src/CMakeLists.txt:95-178); -DBA_SCALAR_FLOAT stands for
  * `typedef float Scalar;` (src/BATypeUtils.h:6-7).  All work happens behind the C ABI of include/ba_mi355x.h.
- * Extension: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking).
+ * Extensions: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking);
+ * BA_CACHE=1 keeps a binary cache `<file>.bacache` of the parsed problem and reuses it when present.
  */
 #define _POSIX_C_SOURCE 199309L
 #include "../../include/ba_mi355x.h"
@@ -45,7 +46,14 @@ int main(int argc, char *argv[])
         return BA_ERR_USAGE;
     }
     ba_problem *p = NULL;
-    int rc = ba_problem_load_bal(argv[1], &p);
+    int rc = -1;
+    char cache[4096];
+    const int use_cache = getenv("BA_CACHE") != NULL && snprintf(cache, sizeof cache, "%s.bacache", argv[1]) < (int)sizeof cache;
+    if (use_cache) rc = ba_problem_load_cache(cache, &p);
+    if (rc != BA_OK) {
+        rc = ba_problem_load_bal(argv[1], &p);
+        if (rc == BA_OK && use_cache) (void)ba_problem_save_cache(p, cache);
+    }
     if (rc == BA_ERR_FILE) {
         fprintf(stderr, "Cannot open %s\n", argv[1]);
         return BA_ERR_FILE;

@@ -68,6 +68,10 @@ int ba_problem_create(int N, int M, int K, const int *cam_idx, const int *pt_idx
  * checkout and for the 1024-camera scaling config; generator described in DESIGN.md). mean_obs is informative only. */
 int ba_problem_synthetic(int N, int M, int K, unsigned long long seed, ba_problem **out);
 int ba_problem_save_bal(const ba_problem *p, const char *path);
+/* Binary cache of a parsed problem (`ifstream >>` / strtod parsing of a 280 MB text file takes seconds; the
+ * cache is the same arrays, little-endian, behind a 32-byte header) -- an extension, the BAL text format stays the interface. */
+int ba_problem_save_cache(const ba_problem *p, const char *path);
+int ba_problem_load_cache(const char *path, ba_problem **out);
 void ba_problem_free(ba_problem *p);
 int ba_problem_dims(const ba_problem *p, int *N, int *M, int *K);
 /* Copies out the arrays (any pointer may be NULL). */

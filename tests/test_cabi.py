@@ -87,6 +87,24 @@ def test_save_load_round_trip_and_unsorted_input(ba, tmp_path):
     assert u.shard_plan(0, 1)["entries"] == p.shard_plan(0, 1)["entries"]
 
 
+def test_binary_cache_round_trip(ba, tmp_path):
+    p = ba.Problem.load_bal(DATA21)
+    f = tmp_path / "p21.bacache"
+    p.save_cache(str(f))
+    q = ba.Problem.load_cache(str(f))
+    a, b = p.arrays(), q.arrays()
+    assert (q.N, q.M, q.K) == (p.N, p.M, p.K) and all(np.array_equal(a[k], b[k]) for k in a)
+    (tmp_path / "bad.bacache").write_bytes(b"not a cache")
+    with pytest.raises(ba.BAError) as e:
+        ba.Problem.load_cache(str(tmp_path / "bad.bacache"))
+    assert e.value.code == 3
+    trunc = tmp_path / "trunc.bacache"
+    trunc.write_bytes(f.read_bytes()[:-100])
+    with pytest.raises(ba.BAError) as e:
+        ba.Problem.load_cache(str(trunc))
+    assert e.value.code == 3
+
+
 def test_synthetic_generator(ba, O):
     p = ba.Problem.synthetic(16, 500, 1800, 42)
     q = ba.Problem.synthetic(16, 500, 1800, 42)
