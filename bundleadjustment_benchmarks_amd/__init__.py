@@ -12,9 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libba_mi355x.so")
 
-QRKIT, QRCHOL, CHOLESKY = 0, 1, 2
+QRKIT, QRCHOL, CHOLESKY, MOREQR = 0, 1, 2, 3
 F64, F32 = 0, 1
-KIND_NAMES = {QRKIT: "QRKIT", QRCHOL: "QRCHOL", CHOLESKY: "CHOLESKY"}
+KIND_NAMES = {QRKIT: "QRKIT", QRCHOL: "QRCHOL", CHOLESKY: "CHOLESKY", MOREQR: "MOREQR"}
 STATUS = {-2: "NotStarted", -1: "Running", 0: "Success", 1: "ExceededLambdaMax", 2: "TooManyFunctionEvaluation",
           3: "MaxItersReached"}
 

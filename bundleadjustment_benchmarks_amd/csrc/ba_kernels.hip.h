@@ -418,9 +418,12 @@ __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__res
         for (int s = 0; s < SL; s++) xn += V[s][c] * V[s][c] + V[s][3 + c] * V[s][3 + c];
         xn = group_sum<T, LPP>(xn);
         const T alpha = sl;                        // the lambda row c is untouched by the earlier reflectors
-        const T beta = -tsqrt(alpha * alpha + xn); // alpha > 0
-        tau[c] = (beta - alpha) / beta;
-        const T sc = (T)1.0 / (alpha - beta);
+        const T beta = -tsqrt(alpha * alpha + xn); // alpha >= 0
+        // beta == 0: a zero column, possible only with lambda = 0 (MOREQR stage 1, point without observations):
+        // identity reflector, zero diagonal entry of R
+        const bool zc = beta == (T)0;
+        tau[c] = zc ? (T)0 : (beta - alpha) / beta;
+        const T sc = zc ? (T)0 : (T)1.0 / (alpha - beta);
 #pragma unroll
         for (int s = 0; s < SL; s++) { V[s][c] *= sc; V[s][3 + c] *= sc; }
         R[c][c] = beta;
@@ -488,6 +491,77 @@ __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__res
             o[36] = 1; o[37] = 1; o[38] = 1;
         }
     }
+}
+
+// MOREQR stage 2 (src/Eigen_ext/BacktrackLevMarqMore.h:297-345: the QR of [R ; sqrt(lambda) I] of every trial).  Stage 1
+// (:288, m_solver.compute(J), once per outer iteration) is k_elim_qr with lambda = 0, which leaves R1_j, -q1_j and
+// R12_i^T in (tri0, tvec0, rec0).  Per point the 6x3 block [sqrt(lambda) I3 ; R1_j] is factored again (three
+// Householder reflectors, lambda rows first); with QR = the 3x3 block of its thin Q that multiplies the R1 rows:
+// Z_i = R12_i^T QR, t = QR^T (-q1), tri = Rt1.  One thread per observation (the 6x3 factorisation is ~150 flops and is
+// recomputed by every observation of the point rather than exchanged); the first observation of a point also
+// writes the point's (tri, t, dinv).
+template <typename T>
+__global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
+                                                    const T *__restrict__ lam, const T *__restrict__ rec0, const T *__restrict__ tri0,
+                                                    const T *__restrict__ tvec0, T *__restrict__ rec, T *__restrict__ dinv,
+                                                    T *__restrict__ tvec, T *__restrict__ tri)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const int j = obs_pt[i];
+    const T sl = tsqrt(*lam);
+    const T r00 = tri0[j], r01 = tri0[(size_t)Ml + j], r02 = tri0[2 * (size_t)Ml + j], r11 = tri0[3 * (size_t)Ml + j],
+            r12 = tri0[4 * (size_t)Ml + j], r22 = tri0[5 * (size_t)Ml + j];
+    T W[3][3] = {{r00, 0, 0}, {r01, r11, 0}, {r02, r12, r22}}; // W[c][r]: column c, R1 rows
+    T Rt[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tau[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const T xn = W[c][0] * W[c][0] + W[c][1] * W[c][1] + W[c][2] * W[c][2];
+        const T beta = -tsqrt(sl * sl + xn); // pivot = lambda row c (untouched by the earlier reflectors), lambda > 0
+        tau[c] = (beta - sl) / beta;
+        const T sc = (T)1.0 / (sl - beta);
+#pragma unroll
+        for (int r = 0; r < 3; r++) W[c][r] *= sc;
+        Rt[c][c] = beta;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 3; c2++) {
+            const T w = (W[c][0] * W[c2][0] + W[c][1] * W[c2][1] + W[c][2] * W[c2][2]) * tau[c];
+            Rt[c][c2] = -w;
+#pragma unroll
+            for (int r = 0; r < 3; r++) W[c2][r] -= W[c][r] * w;
+        }
+    }
+    T Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, QR[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int h = 2; h >= 0; h--)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const T w = (Ql[h][c] + W[h][0] * QR[0][c] + W[h][1] * QR[1][c] + W[h][2] * QR[2][c]) * tau[h];
+            Ql[h][c] -= w;
+#pragma unroll
+            for (int r = 0; r < 3; r++) QR[r][c] -= W[h][r] * w;
+        }
+    const T m0 = tvec0[j], m1 = tvec0[(size_t)Ml + j], m2 = tvec0[2 * (size_t)Ml + j];
+    T t[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) t[c] = QR[0][c] * m0 + QR[1][c] * m1 + QR[2][c] * m2;
+    if (i == pt_ptr[j]) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = t[c]; }
+        tri[j] = Rt[0][0]; tri[(size_t)Ml + j] = Rt[0][1]; tri[2 * (size_t)Ml + j] = Rt[0][2];
+        tri[3 * (size_t)Ml + j] = Rt[1][1]; tri[4 * (size_t)Ml + j] = Rt[1][2]; tri[5 * (size_t)Ml + j] = Rt[2][2];
+    }
+    const T *z = rec0 + (size_t)i * BA_REC;
+    T *o = rec + (size_t)i * BA_REC;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const T a0 = z[3 * c], a1 = z[3 * c + 1], a2 = z[3 * c + 2];
+        const T z0 = a0 * QR[0][0] + a1 * QR[1][0] + a2 * QR[2][0], z1 = a0 * QR[0][1] + a1 * QR[1][1] + a2 * QR[2][1],
+                z2 = a0 * QR[0][2] + a1 * QR[1][2] + a2 * QR[2][2];
+        o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
+        o[27 + c] = z0 * t[0] + z1 * t[1] + z2 * t[2];
+    }
+    o[36] = 1; o[37] = 1; o[38] = 1;
 }
 
 // ---- K5: Schur complement / reduced camera matrix, pair-owner form -------------------------------------------

@@ -33,7 +33,8 @@ constexpr int NB = BA_NB;    // block-column width of the dense LDL^T
 constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 = spare
 constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
-       SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */ };
+       SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
+       SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */ };
 enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_N };
 
 template <typename T> struct DevBuf {
@@ -106,7 +107,7 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
     // state and work arrays
-    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
+    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri, d_rec0, d_dinv0, d_tvec0, d_tri0,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
@@ -179,6 +180,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
         AL(d_gc, (size_t)D); AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
+        if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
         AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)2 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
@@ -248,6 +250,8 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T0], st));
         launch_eval(true, cur);
         launch_grad();
+        if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
+            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p);
         ba_red_jobs jobs{};
         int nj = 0;
         jobs.j[nj++] = {d_part_e.p, gK, 0, SC_ENERGY};
@@ -278,8 +282,12 @@ template <typename T> struct Solver final : SolverBase {
         if (kind == BA_CHOLESKY) {
             hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
                                d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+        } else if (kind == BA_MOREQR) {
+            if (Kl > 0) // BacktrackLevMarqMore.h:297-345, the per-trial QR of [R ; sqrt(lambda) I]
+                hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
+                                   d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            launch_elim_qr();
+            launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         }
     }
 
@@ -287,10 +295,10 @@ template <typename T> struct Solver final : SolverBase {
     // register kernel -- ba_solver_create refuses such a problem for the QR symbols)
     int lpp() const { return sx.kmax <= 32 ? 8 : sx.kmax <= 64 ? 16 : sx.kmax <= 128 ? 32 : 64; }
 
-    void launch_elim_qr()
+    void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri)
     {
 #define BA_QR(L) hipLaunchKernelGGL((k_elim_qr<T, L>), dim3(((size_t)Ml * L + 255) / 256), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jc.p, \
-                                    d_Jp.p, d_r.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p)
+                                    d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri)
         if (Ml <= 0) return; // an empty shard owns no points
         switch (lpp()) {
         case 8: BA_QR(8); break;
@@ -640,7 +648,8 @@ template <typename T> struct Solver final : SolverBase {
             if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
             fun_evals++;
             energy = (T)e;
-            if (iter == 1) lambda = (T)(1e-12 * dmax); // :278-280 / Cholesky.h:263-265
+            if (iter == 1) // :278-280 / Cholesky.h:263-265; MOREQR: 1e-6 * max column norm (BacktrackLevMarqMore.h:272-284)
+                lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
             while (true) {
                 if (lm.max_trials > 0 && trials >= lm.max_trials) { stop = true; status = BA_RUNNING; break; }
                 const auto t0 = std::chrono::steady_clock::now();
@@ -765,7 +774,7 @@ int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar,
                      ba_solver **out)
 {
     if (!p || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return BA_ERR_ARG;
-    if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY) return BA_ERR_ARG;
+    if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY && kind != BA_MOREQR) return BA_ERR_ARG;
     if (scalar != BA_F64 && scalar != BA_F32) return BA_ERR_ARG;
     *out = nullptr;
     int cnt = 0;

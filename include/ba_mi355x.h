@@ -34,8 +34,10 @@ enum {
     BA_ERR_COMM = 7
 };
 
-/* Solver symbols of the reference build (src/CMakeLists.txt:95-178; src/Optimization/BAFunctor.h:98-117). */
-typedef enum { BA_QRKIT = 0, BA_QRCHOL = 1, BA_CHOLESKY = 2 } ba_solver_kind;
+/* Solver symbols of the reference build (src/CMakeLists.txt:95-178; src/Optimization/BAFunctor.h:98-117).
+ * BA_MOREQR (src/Eigen_ext/BacktrackLevMarqMore.h): two QR factorisations per step -- J once per outer iteration,
+ * [R ; sqrt(lambda) I] per trial -- and lambda0 = 1e-6 * max column norm of J. */
+typedef enum { BA_QRKIT = 0, BA_QRCHOL = 1, BA_CHOLESKY = 2, BA_MOREQR = 3 } ba_solver_kind;
 
 /* `typedef double Scalar;` / `typedef float Scalar;` (src/BATypeUtils.h:6-7). */
 typedef enum { BA_F64 = 0, BA_F32 = 1 } ba_scalar;

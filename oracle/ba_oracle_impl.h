@@ -400,6 +400,10 @@ static void FN(elim_qr)(int M, const int *pt_ptr, const S *Jc, const S *Jp, cons
             for (int r = c + 1; r < m; r++) xn += col[r] * col[r];
             const S alpha = col[c];
             S beta = SQRT(alpha * alpha + xn);
+            if (beta == (S)0) { /* zero column (only with lambda = 0, MOREQR stage 1): identity reflector */
+                tau[c] = 0;
+                continue;
+            }
             if (alpha > 0) beta = -beta;
             tau[c] = (beta - alpha) / beta;
             const S sc = (S)1.0 / (alpha - beta);
@@ -455,6 +459,80 @@ static void FN(elim_qr)(int M, const int *pt_ptr, const S *Jc, const S *Jp, cons
     }
     free(Wk);
     free(Q);
+}
+
+/* MOREQR (src/Eigen_ext/BacktrackLevMarqMore.h:204-425, README.md:16 "performing 2 QR decompositions in each step"):
+ * stage 1, once per outer iteration (:288 m_solver.compute(J)): per point the Householder QR of (Jp)_j (2k_j x 3) ->
+ *   R1_j, thin Q1, R12_i = Q1_i^T A_i, q1 = Q1^T r.  Computed by elim_qr with lambda = 0, i.e. as the QR of
+ *   [(Jp)_j ; 0_3]: the same factorisation, and no special cases for points with fewer than two observations (a
+ *   column that is already zero gets the identity reflector and a zero diagonal entry of R1);
+ * stage 2, per trial (:297-345 QR of [R ; sqrt(lambda) I]): per point the QR of [sqrt(lambda) I3 ; R1_j] (6 x 3) ->
+ *   Rt1_j and the 3x3 block QR of its thin Q that multiplies the R1 rows; Z_i = R12_i^T QR, t = QR^T (-q1).
+ * The reduced camera system is then the same expression as for QRCHOL (the algebra is in DESIGN.md). */
+typedef struct {
+    S *R12T; /* K x 27: R12_i^T (9x3 row-major) */
+    S *R1;   /* M x 6 upper triangle 00 01 02 11 12 22 */
+    S *mq1;  /* M x 3: -q1 */
+} FN(more_t);
+
+static void FN(more_outer)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, FN(more_t) * o)
+{
+    FN(elim_t) e;
+    int K = pt_ptr[M];
+    e.Z = o->R12T; e.tri = o->R1; e.t = o->mq1;
+    e.dinv = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
+    (void)K;
+    FN(elim_qr)(M, pt_ptr, Jc, Jp, fvec, (S)0, &e, NULL, NULL); /* lambda = 0: QR of [B;0] */
+    free(e.dinv);
+}
+
+static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) * o, FN(elim_t) * e)
+{
+    const S sl = SQRT(lambda);
+    for (int j = 0; j < M; j++) {
+        /* QR of [sl I3 ; R1] (6x3), lambda rows first; column-major work array W[c][row] */
+        const S *R1 = o->R1 + 6 * (size_t)j;
+        S W[3][6] = {{sl, 0, 0, R1[0], 0, 0}, {0, sl, 0, R1[1], R1[3], 0}, {0, 0, sl, R1[2], R1[4], R1[5]}};
+        S tau[3], Rt[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int c = 0; c < 3; c++) {
+            S xn = 0;
+            for (int r = 3; r < 6; r++) xn += W[c][r] * W[c][r];
+            const S alpha = sl; /* the lambda row c is untouched by the earlier reflectors */
+            const S beta = -SQRT(alpha * alpha + xn);
+            tau[c] = (beta - alpha) / beta;
+            const S sc = (S)1.0 / (alpha - beta);
+            for (int r = 3; r < 6; r++) W[c][r] *= sc;
+            Rt[c][c] = beta;
+            for (int c2 = c + 1; c2 < 3; c2++) {
+                S w = 0;
+                for (int r = 3; r < 6; r++) w += W[c][r] * W[c2][r];
+                w *= tau[c];
+                Rt[c][c2] = -w;
+                for (int r = 3; r < 6; r++) W[c2][r] -= W[c][r] * w;
+            }
+        }
+        /* thin Q: lambda rows Ql (not needed), R1 rows QR[r][c] */
+        S Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, QR[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int h = 2; h >= 0; h--)
+            for (int c = 0; c < 3; c++) {
+                S w = Ql[h][c];
+                for (int r = 0; r < 3; r++) w += W[h][3 + r] * QR[r][c];
+                w *= tau[h];
+                Ql[h][c] -= w;
+                for (int r = 0; r < 3; r++) QR[r][c] -= W[h][3 + r] * w;
+            }
+        S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j, *tri = e->tri + 6 * (size_t)j;
+        const S *mq1 = o->mq1 + 3 * (size_t)j;
+        dinv[0] = dinv[1] = dinv[2] = 1;
+        for (int c = 0; c < 3; c++) t[c] = QR[0][c] * mq1[0] + QR[1][c] * mq1[1] + QR[2][c] * mq1[2];
+        tri[0] = Rt[0][0]; tri[1] = Rt[0][1]; tri[2] = Rt[0][2]; tri[3] = Rt[1][1]; tri[4] = Rt[1][2]; tri[5] = Rt[2][2];
+        for (int i = pt_ptr[j]; i < pt_ptr[j + 1]; i++) {
+            const S *Z0 = o->R12T + 27 * (size_t)i;
+            S *Z = e->Z + 27 * (size_t)i;
+            for (int c = 0; c < 9; c++)
+                for (int m = 0; m < 3; m++) Z[3 * c + m] = Z0[3 * c] * QR[0][m] + Z0[3 * c + 1] * QR[1][m] + Z0[3 * c + 2] * QR[2][m];
+        }
+    }
 }
 
 /* Reduced camera system from the elimination workspace.
@@ -619,7 +697,7 @@ static void FN(grad_diag)(int N, int M, int K, const int *cam_idx, const int *pt
     if (diagmax) *diagmax = dm;
 }
 
-/* One LM trial's linear solve: dx (3M+9N) from J, r, lambda.  kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY.
+/* One LM trial's linear solve: dx (3M+9N) from J, r, lambda.  kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY, 3 MOREQR.
  * Optional outputs (may be NULL): Sout D*D col-major, rhsout D, gout 3M+9N (= -J^T r, the reference's JtRes,
  * BacktrackLevMarqQRChol.h:267), diagmax = max diag(J^T J) (:270-280). */
 int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp,
@@ -649,6 +727,16 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     int rc = 0;
     if (kind == 2) {
         FN(elim_cholesky)(M, pt_ptr, Jc, Jp, fvec, lambda, &e);
+    } else if (kind == 3) {
+        /* the outer factorisation is redone per call here (the reference does it once per outer iteration,
+         * BacktrackLevMarqMore.h:288; same numbers) */
+        FN(more_t) o;
+        o.R12T = (S *)malloc(sizeof(S) * 27 * (size_t)(K > 0 ? K : 1));
+        o.R1 = (S *)malloc(sizeof(S) * 6 * (size_t)(M > 0 ? M : 1));
+        o.mq1 = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
+        FN(more_outer)(M, pt_ptr, Jc, Jp, fvec, &o);
+        FN(more_trial)(M, pt_ptr, lambda, &o, &e);
+        free(o.R12T); free(o.R1); free(o.mq1);
     } else {
         if (kind == 0) {
             Q1obs = (S *)malloc(sizeof(S) * 6 * (size_t)K);
@@ -712,8 +800,9 @@ int FN(ora_minimize)(int kind, int N, int M, int K, const int *cam_idx, const in
         {
             S dmax = 0;
             FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, g, &dmax);
-            /* lambda0 = 1e-12 * max diag(J^T J) (BacktrackLevMarqQRChol.h:278-280; ...Cholesky.h:263-265) */
-            if (iter == 1) lambda = (S)(1e-12 * (double)dmax);
+            /* lambda0 = 1e-12 * max diag(J^T J) (BacktrackLevMarqQRChol.h:278-280; ...Cholesky.h:263-265);
+             * MOREQR: 1e-6 * max column norm (BacktrackLevMarqMore.h:272-284) */
+            if (iter == 1) lambda = kind == 3 ? (S)(1e-6 * sqrt((double)dmax)) : (S)(1e-12 * (double)dmax);
         }
         while (1) {
             if (ntr >= max_trials) { stop = 1; status = -1; break; }

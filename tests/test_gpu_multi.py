@@ -49,7 +49,7 @@ def _worker(rank, world, port, kind, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 @pytest.mark.timeout(600)
 def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
     p = ba.Problem.synthetic(24, 3000, 10500, 77)
@@ -107,7 +107,7 @@ def test_empty_shard_does_not_fault(ba, gpu_ok):
     plans = [p.shard_plan(r, 8) for r in range(8)]
     empty = [r for r, q in enumerate(plans) if q["p1"] == q["p0"]]
     assert empty
-    for kind in (ba.CHOLESKY, ba.QRCHOL):
+    for kind in (ba.CHOLESKY, ba.QRCHOL, ba.MOREQR):
         s = ba.Solver(p, kind, ba.F64, shard_rank=empty[0], shard_world=8)
         s.set_allreduce(lambda ptr, count, scalar, op, stream: 0)  # stands in for the sum over the other (absent) ranks
         e, _ = s.linearize()

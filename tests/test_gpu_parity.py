@@ -45,7 +45,7 @@ def test_linearize_matches_oracle(ba, O, gpu_ok, prob21, scalar, tol):
     assert relmax(cams_dev, cam) < (1e-15 if scalar == 0 else 1e-6)
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     po = to_oracle(prob21)
     cam = O.init_cams(po)
@@ -54,7 +54,7 @@ def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     s = ba.Solver(prob21, kind, ba.F64)
     s.keep_intermediates(True)
     eg, dmax = s.linearize()
-    lam = 1e-12 * dmax
+    lam = 1e-6 * np.sqrt(dmax) if kind == ba.MOREQR else 1e-12 * dmax  # the symbols' own lambda0
     st = O.step(kind, po, Jc, Jp, f, lam)
     et, rho_scale, dxn = s.try_step(lam)
     S = s.get(ba.GET_S)
@@ -82,7 +82,7 @@ def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     assert relmax(s.get(ba.GET_POINTS_TEST), pt) < 1e-7
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 def test_lm_free_running_prefix_f64(ba, O, gpu_ok, prob21, kind):
     """Free-running LM: identical accept/reject sequence and energies to 1e-7 over the first 5 table rows.
     Beyond that the trajectory is chaotic (cond(S) ~ 3e11: two correct fp64 solvers drift apart by ~10x per
@@ -102,7 +102,7 @@ def test_lm_free_running_prefix_f64(ba, O, gpu_ok, prob21, kind):
     assert rg["status"] == ro["status"] == -1
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 def test_lm_per_trial_injected_state_f64(ba, O, gpu_ok, prob21, kind):
     """Per-trial parity along the oracle's trajectory: before each of the first 24 trials the oracle's state x and
     lambda are injected; energy (1e-12), test energy (max(3e-9, 1e-11/lambda)) and, while lambda >= 1e-5, the accept
@@ -146,7 +146,7 @@ def test_stats_match_oracle(ba, O, gpu_ok, prob21):
         assert abs(sg[k] - st[k]) < 1e-12 * abs(st[k])
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
     po = to_oracle(small)
     cam = O.init_cams(po)
@@ -164,7 +164,7 @@ def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
 
 
-@pytest.mark.parametrize("kind", [2, 1, 0])
+@pytest.mark.parametrize("kind", [2, 1, 0, 3])
 def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
     """Scalar = float (src/BATypeUtils.h:6-7): one trial against the float oracle with the same elimination order.
     fp32 leaves ~1e-3 on S (entries up to 1e9 accumulated from ~1e3 terms) and, through cond(S), a few percent on dx;
@@ -215,7 +215,7 @@ def _ragged_problem(ba):
     return ba.Problem.from_arrays(p.N, p.M, int(keep.sum()), cam_idx, pt_idx, meas, a["cams9"], a["pts"])
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 3])
 def test_ragged_and_unsorted_input(ba, O, gpu_ok, kind):
     p = _ragged_problem(ba)
     a = p.arrays()
@@ -250,7 +250,7 @@ def test_tiny_problem_and_minimal_sizes(ba, O, gpu_ok):
     cam = O.init_cams(po)
     f, e = O.residuals(po, cam, po.pts)
     Jc, Jp = O.jacobian(po, cam, po.pts)
-    for kind in (2, 1):
+    for kind in (2, 1, 3):
         s = ba.Solver(p, kind, ba.F64)
         eg, _ = s.linearize()
         assert abs(eg - e) <= 1e-12 * max(e, 1e-300)

@@ -54,9 +54,9 @@ def test_jacobian_finite_differences(O, small):
     assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize("kind", [2, 1, 0])
+@pytest.mark.parametrize("kind", [2, 1, 0, 3])
 def test_step_solves_normal_equations(O, small, kind):
-    """All three symbols solve (J'J + lambda I) dx = -J'r (QR of [J; sqrt(lambda) I] == normal equations)."""
+    """All four symbols solve (J'J + lambda I) dx = -J'r (QR of [J; sqrt(lambda) I] == normal equations)."""
     p = small
     cam = O.init_cams(p)
     f, _ = O.residuals(p, cam, p.pts)
@@ -84,7 +84,7 @@ def test_three_symbols_agree(O, small):
     f, _ = O.residuals(p, cam, p.pts)
     Jc, Jp = O.jacobian(p, cam, p.pts)
     ref = O.step(O.CHOLESKY, p, Jc, Jp, f, 1e-4)["dx"]
-    for kind in (O.QRCHOL, O.QRKIT):
+    for kind in (O.QRCHOL, O.QRKIT, O.MOREQR):
         dx = O.step(kind, p, Jc, Jp, f, 1e-4)["dx"]
         assert np.linalg.norm(dx - ref) < 1e-7 * np.linalg.norm(ref)
 
