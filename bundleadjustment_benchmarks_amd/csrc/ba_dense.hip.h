@@ -116,9 +116,9 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 // Every workgroup factors the 64x64 diagonal block itself (it is the critical path; a broadcast would cost a kernel
 // boundary).  The pivot recurrence d_k -> 1/d_k -> l_ik -> d_k+1 is pure latency on this machine (a dependent f64 FMA
 // is ~32 cycles, one wave issues an f64 op every ~9 cycles), so the block is processed in four 16-wide sub-panels:
-//   A1  ONE wave factors the 16x16 diagonal tile in registers (4 entries per lane) and inverts it with the same row
-//       operations; no barriers; the pivot is broadcast with v_readlane so the reciprocal chain (estimate + Newton)
-//       starts before the LDS exchange of the column has finished;
+//   A1  wave 0 factors the 16x16 diagonal tile in registers (4 entries per lane), wave 1 inverts it with the same row
+//       operations one pivot behind (LDS progress word, no barriers); the pivot is broadcast with v_readlane so the
+//       reciprocal chain (estimate + Newton) starts before the LDS exchange of the column has finished;
 //   A2  the tiles below (inside the 64x64 block) get Y = X W_ss^T on the matrix cores;
 //   A3  the remaining tiles of the block get the rank-16 update on the matrix cores.
 // W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
@@ -138,6 +138,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     T (*Ts)[16][17] = reinterpret_cast<T (*)[16][17]>(YsTs);
     static_assert(3 * 16 * 17 <= 16 * (NB + 1), "Ts must fit into Ys");
     __shared__ T colx4[4][16], wtile[16][17], dinv[NB], junkbuf[64];
+    __shared__ int prog[64]; // A1 hand-off: pivots of the diagonal block whose multipliers are in Ad (per lane)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -146,7 +147,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         Ad[c][r] = S[(size_t)(p0 + lo) * ld + p0 + hi]; // mirror the lower triangle
         Wl[c][r] = (T)0;
     }
-    if (tid < NB) dinv[tid] = (T)0;
+    if (tid < NB) { dinv[tid] = (T)0; prog[tid] = 0; }
     __syncthreads();
     if (Wprev) {
         // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other
@@ -198,52 +199,70 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int c0 = 16 * s;
         const int np = min(16, nb - c0); // pivots in this sub-panel
         if (np <= 0) break;              // uniform
-        // ---- A1: 16x16 diagonal tile, wave 0, lane (i, q) owns row i, columns 4q .. 4q+3.
-        // A single wave issues one f64-class VALU instruction every ~8 cycles, so the loop is written for instruction
-        // count: every LDS store is unconditional (lanes that do not own the datum store to a scratch slot instead of
-        // being masked off), the multipliers leave the registers for LDS as soon as they exist, so the rank-1 update
-        // needs no masks on the already finished columns.
+        // ---- A1: 16x16 diagonal tile; lane (i, q) owns row i, columns 4q .. 4q+3.
+        // A single wave issues one f64-class VALU instruction every ~8 cycles and the pivot loop is bound by that issue
+        // rate, so the work of a pivot is split over two waves (two SIMDs):
+        //   wave 0 factors the tile (column k -> LDS, pivot by v_readlane, reciprocal, multipliers, rank-1 update) and
+        //          never waits for anybody; the multipliers go straight to their final place in Ad and a per-lane progress
+        //          word tells wave 1 that column k is there (LDS executes a wave's instructions in order);
+        //   wave 1 applies the same row operations to I (W_ss = L_ss^-1), one pivot behind.
+        // D(k) stays in its register until the end (row k is never touched after pivot k); 1/D(k) is recomputed there by
+        // the same instruction sequence, so the loop stores nothing but the multipliers.
         if (wv == 0) {
             const int i = li, q = lk;
-#ifdef BA_STAMP2
-            unsigned long long st2_t0 = 0, st2_t1 = 0; long long st2_acc[4] = {0, 0, 0, 0};
-#endif
-            T a[4], w[4];
+            T a[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                a[c] = Ad[c0 + 4 * q + c][c0 + i];
-                w[c] = (4 * q + c == i) ? (T)1 : (T)0;
-            }
+            for (int c = 0; c < 4; c++) a[c] = Ad[c0 + 4 * q + c][c0 + i];
+            ba_wave_lds_sync(); // the multipliers overwrite the tile: every lane has its entries first
             T *const junk = junkbuf + lane; // per-lane scratch slot
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < np) { // uniform
                     const int kq = k >> 2, kc = k & 3;
-                    BA_STAMP2_GET(st2_t0);
-                    colx4[q][i] = a[kc];                       // column k is the kc-th register of the lanes with q == kq
-#pragma unroll
-                    for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
-                    BA_STAMP2_SEG(0);
+                    colx4[q][i] = a[kc];                          // column k is the kc-th register of the lanes with q == kq
                     const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
                     const T r = ba_rcp(dk);
-                    BA_STAMP2_SEG(1);
                     ba_wave_lds_sync();
                     const T lraw = colx4[kq][i];
-                    T y[4], wk[4];
+                    T y[4];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { y[c] = colx4[kq][4 * q + c]; wk[c] = wtile[k][4 * q + c]; }
-                    BA_STAMP2_SEG(2);
-                    const T l = (i > k) ? lraw * r : (T)0;
+                    for (int c = 0; c < 4; c++) y[c] = colx4[kq][4 * q + c];
+                    const T lm = (i > k) ? lraw : (T)0; // off the reciprocal's dependency chain
+                    const T l = lm * r;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        a[c] -= l * y[c]; // columns <= k are dead from here on (their multipliers live in Ad)
-                        w[c] -= l * wk[c];
-                    }
-                    *((q == kq && i > k) ? &Ad[c0 + k][c0 + i] : junk) = l;     // L(i, k)
-                    *((lane == 0) ? &dinv[c0 + k] : junk) = r;
-                    *((lane == 0) ? &Ad[c0 + k][c0 + k] : junk) = dk;           // D(k)
+                    for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
+                    *((q == kq) ? &Ad[c0 + k][c0 + i] : junk) = l; // L(i, k); zero on and above the diagonal
+                    __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
-                    BA_STAMP2_SEG(3);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (4 * q + c == i && i < np) {
+                    Ad[c0 + i][c0 + i] = a[c]; // D(i)
+                    dinv[c0 + i] = ba_rcp(a[c]);
+                }
+        } else if (wv == 1) {
+            const int i = li, q = lk;
+            T w[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < np) { // uniform
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
+                    while (__hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * s + k + 1)
+                        __builtin_amdgcn_s_sleep(1); // column k of L is in Ad
+                    ba_wave_lds_sync();
+                    const T lr = Ad[c0 + k][c0 + i];
+                    const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
+                    T wk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
+                    ba_wave_lds_sync();
                 }
             }
 #pragma unroll
@@ -251,19 +270,16 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 const int j = 4 * q + c;
                 Wl[c0 + i][c0 + j] = (j <= i) ? w[c] : (T)0;
             }
-#ifdef BA_STAMP2
-            if (blk == 0 && lane == 0) for (int q2 = 0; q2 < 4; q2++) ba_stamp_acc[32 + 4 * s + q2] = st2_acc[q2];
-#endif
         } else {
-            if (own_rows) { // look-ahead update of the rows below, hidden under A1(0) (quadrants 0..2) and A1(1) (quadrant 3)
+            const int h = wv - 2;
+            if (own_rows && s < 2) { // look-ahead update of the rows below, hidden under A1(0) and A1(1)
                 // INL: inlined (fastest, but ~250 VGPRs: one workgroup per CU) or out of line (116 VGPRs: two per CU)
-                const int quad = (s == 0) ? wv - 1 : (s == 1 && wv == 1) ? 3 : -1;
-                if (quad >= 0) {
-                    if (INL) ba_update_quad<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, quad);
-                    else ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, quad);
-                }
+                const int quad = 2 * s + h;
+                if (INL) ba_update_quad<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, quad);
+                else ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, quad);
             }
-            if (s >= 2 && wv - 1 < s - 1) w_tile(s - 1, wv - 1, wv - 1); // row s-1 of W, block column wv-1
+            if (s == 2 && h == 0) w_tile(1, 0, 0); // row s-1 of W
+            if (s == 3) w_tile(2, h, h);
         }
         __syncthreads();
         BA_STAMP_SEG(0);
