@@ -56,11 +56,13 @@ __device__ __forceinline__ float ba_rcp(float d)
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
-#define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); } /* own work before a barrier */
 #define BA_STAMP_GET(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define BA_STAMP_SEG(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); st_t0 = st_t1; }
 #else
 #define BA_STAMP_DECL
+#define BA_STAMP_OWN(i)
 #define BA_STAMP_GET(v)
 #define BA_STAMP_SEG(i)
 #endif
@@ -252,14 +254,15 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 if (k < np) { // uniform
 #pragma unroll
                     for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
-                    while (__hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * s + k + 1)
-                        __builtin_amdgcn_s_sleep(1); // column k of L is in Ad
+                    ba_wave_lds_sync();
+                    T wk[4]; // row k of W is final since pivot k - 1: fetched before the wait for wave 0
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
+                    // column k of L is in Ad?  (no s_sleep: its 64-cycle granularity is a whole LDS round trip)
+                    while (__hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * s + k + 1) {}
                     ba_wave_lds_sync();
                     const T lr = Ad[c0 + k][c0 + i];
                     const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
-                    T wk[4];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
 #pragma unroll
                     for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
                     ba_wave_lds_sync();
@@ -281,6 +284,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             if (s == 2 && h == 0) w_tile(1, 0, 0); // row s-1 of W
             if (s == 3) w_tile(2, h, h);
         }
+        BA_STAMP_OWN(6);
         __syncthreads();
         BA_STAMP_SEG(0);
         if (s == 3 || c0 + 16 >= NB) break;
@@ -382,7 +386,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #ifdef BA_STAMP
     BA_STAMP_SEG(5);
     if (blk == 0 && lane == 0)
-        for (int q = 0; q < 6; q++) ba_stamp_acc[8 * wv + q] = st_acc[q];
+        for (int q = 0; q < 7; q++) ba_stamp_acc[8 * wv + q] = st_acc[q];
 #endif
 }
 
