@@ -56,13 +56,19 @@ __device__ __forceinline__ float ba_rcp(float d)
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
-#define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); } /* own work before a barrier */
+#define BA_STAMP_PRO0 unsigned long long st_p0; BA_STAMP_GET(st_p0);
+#define BA_STAMP_PRO unsigned long long st_p1; BA_STAMP_GET(st_p1); const long long st_pro = (long long)(st_p1 - st_p0);
+#define BA_STAMP_FLUSH if (blk == 0 && (threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; q_++) ba_stamp_acc[8 * (threadIdx.x >> 6) + q_] = st_acc[q_]; ba_stamp_acc[8 * (threadIdx.x >> 6) + 7] = st_pro; }
 #define BA_STAMP_GET(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define BA_STAMP_SEG(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); st_t0 = st_t1; }
 #else
 #define BA_STAMP_DECL
 #define BA_STAMP_OWN(i)
+#define BA_STAMP_PRO
+#define BA_STAMP_PRO0
+#define BA_STAMP_FLUSH
 #define BA_STAMP_GET(v)
 #define BA_STAMP_SEG(i)
 #endif
@@ -143,13 +149,24 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     __shared__ int prog[64]; // A1 hand-off: pivots of the diagonal block whose multipliers are in Ad (per lane)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx % NB, c = idx / NB;
-        const int lo = min(r, c), hi = max(r, c);
-        Ad[c][r] = S[(size_t)(p0 + lo) * ld + p0 + hi]; // mirror the lower triangle
-        Wl[c][r] = (T)0;
+    BA_STAMP_PRO0
+    // Tile fills: all global loads of a fill are issued before the first LDS store (a load -> store loop pays the L2 round
+    // trip once per iteration: 16 x ~800 cycles for one 64 x 64 tile).
+    constexpr int NF = NB * NB / 256;
+    T fa[NF];
+#pragma unroll
+    for (int it = 0; it < NF; it++) {
+        const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
+        fa[it] = S[(size_t)(p0 + min(r, c)) * ld + p0 + max(r, c)]; // mirror the lower triangle
     }
     if (tid < NB) { dinv[tid] = (T)0; prog[tid] = 0; }
+    typedef typename ba_acc<T>::type acc_t;
+#pragma unroll
+    for (int it = 0; it < NF; it++) {
+        const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
+        Ad[c][r] = fa[it];
+        Wl[c][r] = (T)0;
+    }
     __syncthreads();
     if (Wprev) {
         // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other
@@ -161,9 +178,9 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         // while wave 0 factors the first two sub-panels (see the A1 stage); every later barrier waits for the stores
         // (s_waitcnt vmcnt(0)), and the GEMM reads them past L1
     }
+    BA_STAMP_PRO
     const int rown = p0 + NB + 64 * blk;
     const bool own_rows = Wprev != nullptr && rown < nrows;
-    typedef typename ba_acc<T>::type acc_t;
     BA_STAMP_DECL
     BA_STAMP_GET(st_t0);
     // Off-diagonal tile W_ts of W = L11^-1 (t > sc): W_ts = -W_tt sum_{u=sc}^{t-1} L_tu W_us, one wave, MFMA products.
@@ -362,10 +379,15 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[t][v] = 0;
+    T xall[NB / 4]; // all sixteen loads in flight before the first MFMA (one L2 round trip instead of four)
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; kk++) // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold
+                                        // the pre-update lines
+        xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < NB / 4; kk++) {
-        // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold the pre-update lines
-        const T xb = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const T xb = xall[kk];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
@@ -383,11 +405,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             Wp[(size_t)j * ld + r0 + li] = yv;
             S[(size_t)(p0 + j) * ld + r0 + li] = yv * dinv[j];
         }
-#ifdef BA_STAMP
     BA_STAMP_SEG(5);
-    if (blk == 0 && lane == 0)
-        for (int q = 0; q < 7; q++) ba_stamp_acc[8 * wv + q] = st_acc[q];
-#endif
+    BA_STAMP_FLUSH
 }
 
 
@@ -452,7 +471,9 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
                 const int cc = 16 * t + ba_crow<T>(lk, v), rr = 16 * u + li;
                 acc[t][u][v] = TOLDS ? Cl[qc + cc][qr + rr] : S[(size_t)(col0 + cc) * ld + row0 + rr];
             }
-    constexpr int CH = (NB / 4 < 8) ? NB / 4 : 8; // k-steps whose operands are in flight together
+    // k-steps whose operands are in flight together: all sixteen for the diagonal block (latency: it is on the critical
+    // path), eight for the trailing tiles (throughput: registers)
+    constexpr int CH = TOLDS ? NB / 4 : ((NB / 4 < 8) ? NB / 4 : 8);
 #pragma unroll
     for (int half = 0; half < (NB / 4) / CH; half++) {
         T a[CH][2], b[CH][2];
@@ -521,6 +542,17 @@ __global__ __launch_bounds__(256) void k_ldlt_backstep(int ncols, int ld, int zr
     __shared__ T zs[NB], xs[NB], part[256 / NB][NB];
     const int tid = threadIdx.x;
     const int nb = min(NB, ncols - p0);
+    // first pass of the elimination loop below: its column entries do not depend on x, so they are requested up front and
+    // arrive under the GEMV (one L2 round trip less per launch; there are nblk launches in a row)
+    const int lane = tid & 63, w = tid >> 6, cq = lane & 15, rq = lane >> 4;
+    const int cb0 = (blockIdx.x * 4 + w) * 16;
+    T cpre[NB / 4];
+    if (cb0 + cq < p0) {
+        const T *col = S + (size_t)(cb0 + cq) * ld + p0 + (NB / 4) * rq;
+#pragma unroll
+        for (int t = 0; t < NB / 4; t++) cpre[t] = col[t];
+    }
+    const T zpre = (cb0 + cq < p0 && rq == 0) ? S[(size_t)(cb0 + cq) * ld + zrow] : (T)0;
     if (tid < NB) zs[tid] = (tid < nb) ? S[(size_t)(p0 + tid) * ld + zrow] : (T)0;
     __syncthreads();
     {
@@ -542,21 +574,25 @@ __global__ __launch_bounds__(256) void k_ldlt_backstep(int ncols, int ld, int zr
     __syncthreads();
     // elimination from the earlier unknowns: a wave takes 16 columns per pass, lane (cq, rq) sums 16 of the 64 rows of
     // column cq (128 contiguous bytes), two butterfly steps combine the four row quarters
-    const int lane = tid & 63, w = tid >> 6, cq = lane & 15, rq = lane >> 4;
     T xr[NB / 4];
 #pragma unroll
     for (int t = 0; t < NB / 4; t++) xr[t] = xs[(NB / 4) * rq + t];
-    for (int cb = (blockIdx.x * 4 + w) * 16; cb < p0; cb += gridDim.x * 64) {
+    for (int cb = cb0; cb < p0; cb += gridDim.x * 64) {
         const int c = cb + cq;
         T a = 0;
         if (c < p0) {
-            const T *col = S + (size_t)c * ld + p0 + (NB / 4) * rq;
+            if (cb == cb0) {
 #pragma unroll
-            for (int t = 0; t < NB / 4; t++) a += col[t] * xr[t];
+                for (int t = 0; t < NB / 4; t++) a += cpre[t] * xr[t];
+            } else {
+                const T *col = S + (size_t)c * ld + p0 + (NB / 4) * rq;
+#pragma unroll
+                for (int t = 0; t < NB / 4; t++) a += col[t] * xr[t];
+            }
         }
         a += __shfl_xor(a, 16, 64);
         a += __shfl_xor(a, 32, 64);
-        if (rq == 0 && c < p0) S[(size_t)c * ld + zrow] -= a;
+        if (rq == 0 && c < p0) S[(size_t)c * ld + zrow] = ((cb == cb0) ? zpre : S[(size_t)c * ld + zrow]) - a;
     }
 }
 

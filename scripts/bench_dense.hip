@@ -116,6 +116,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(2), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
     CK(hipStreamSynchronize(st));
     long long hs[64]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_stamp_acc), sizeof(hs)));
+    for (int w = 0; w < 4; w++) printf("classic panel wave %d: preamble %lld\n", w, hs[8 * w + 7]);
 #ifdef BA_STAMP2
     for (int sp = 0; sp < 4; sp++) printf("sub-panel %d, cycles per pivot: publish %.0f  readlane+rcp %.0f  lds-read %.0f  fma+store %.0f\n", sp, hs[32 + 4 * sp] / 16.0, hs[32 + 4 * sp + 1] / 16.0, hs[32 + 4 * sp + 2] / 16.0, hs[32 + 4 * sp + 3] / 16.0);
 #endif
