@@ -596,4 +596,101 @@ __global__ __launch_bounds__(256) void k_ldlt_backstep(int ncols, int ld, int zr
     }
 }
 
+// Backward sweep, two block columns per launch (blocks pb and pb + 1; the per-launch cost of k_ldlt_backstep is three
+// dependent L2 round trips plus the kernel boundary, not arithmetic).  Every operand that does not depend on x -- both
+// inverses, the coupling block L(pb + 1, pb), the first pass of the elimination columns -- is requested before the first
+// barrier; the launch then has ONE exposed round trip and a chain of LDS phases:
+//   x1 = W1^T z1;  z0 -= L10^T x1;  x0 = W0^T z0;  z_c -= sum_r L(r, c) [x0; x1](r)  for the earlier columns c.
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void k_ldlt_backpair(int ncols, int ld, int zrow, int pb, T *__restrict__ S, const T *__restrict__ Winv,
+                                                       T *__restrict__ x)
+{
+    static_assert(NB == 64, "written for 64-wide block columns");
+    __shared__ T zs[2][NB], xs[2 * NB], part[4][NB];
+    const int tid = threadIdx.x, j = tid & 63, q = tid >> 6;
+    const int p0 = pb * NB, p1 = p0 + NB;
+    const T *W0 = Winv + (size_t)pb * NB * NB, *W1 = W0 + (size_t)NB * NB;
+    T w1[16], w0[16], l10[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int k = 16 * q + t;
+        w1[t] = W1[k * NB + j];                       // W1[k][j]
+        w0[t] = W0[k * NB + j];
+        l10[t] = S[(size_t)(p0 + j) * ld + p1 + k];   // L(p1 + k, p0 + j)
+    }
+    // elimination columns of the first pass: lane (cq, rq) sums the rq-th quarter of the 128 rows of column cq
+    const int lane = tid & 63, w = tid >> 6, cq = lane & 15, rq = lane >> 4;
+    const int cb0 = (blockIdx.x * 4 + w) * 16;
+    T cpre[32];
+    const bool have0 = cb0 + cq < p0;
+    if (have0) {
+        const T *col = S + (size_t)(cb0 + cq) * ld + p0 + 32 * rq;
+#pragma unroll
+        for (int t = 0; t < 32; t++) cpre[t] = col[t];
+    }
+    const T zpre = (have0 && rq == 0) ? S[(size_t)(cb0 + cq) * ld + zrow] : (T)0;
+    if (tid < 2 * NB) {
+        const int c = p0 + tid;
+        zs[tid >> 6][tid & 63] = (c < ncols) ? S[(size_t)c * ld + zrow] : (T)0;
+    }
+    __syncthreads();
+    T a = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) a += w1[t] * zs[1][16 * q + t];
+    part[q][j] = a;
+    __syncthreads();
+    if (tid < NB) xs[NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    __syncthreads();
+    a = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) a += l10[t] * xs[NB + 16 * q + t];
+    part[q][j] = a;
+    __syncthreads();
+    if (tid < NB) zs[0][tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    __syncthreads();
+    a = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) a += w0[t] * zs[0][16 * q + t];
+    part[q][j] = a;
+    __syncthreads();
+    if (tid < NB) xs[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 2 * NB && p0 + tid < ncols) x[p0 + tid] = xs[tid];
+    T xr[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) xr[t] = xs[32 * rq + t];
+    for (int cb = cb0; cb < p0; cb += gridDim.x * 64) {
+        const int c = cb + cq;
+        T s_ = 0;
+        if (c < p0) {
+            if (cb == cb0) {
+#pragma unroll
+                for (int t = 0; t < 32; t++) s_ += cpre[t] * xr[t];
+            } else {
+                const T *col = S + (size_t)c * ld + p0 + 32 * rq;
+#pragma unroll
+                for (int t = 0; t < 32; t++) s_ += col[t] * xr[t];
+            }
+        }
+        s_ += __shfl_xor(s_, 16, 64);
+        s_ += __shfl_xor(s_, 32, 64);
+        if (rq == 0 && c < p0) S[(size_t)c * ld + zrow] = ((cb == cb0) ? zpre : S[(size_t)c * ld + zrow]) - s_;
+    }
+}
+
+// Host side of the backward sweep on `st`: pairs of block columns from the bottom, a single block column left over at the top.
+template <typename T, int NB>
+inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x)
+{
+    const int nblk = (ncols + NB - 1) / NB;
+    int p = nblk - 1;
+    for (; p >= 1; p -= 2) {
+        const int pb = p - 1;
+        int g = pb; // 64 earlier columns per workgroup
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL((k_ldlt_backpair<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, zrow, pb, S, Winv, x);
+    }
+    if (p == 0) hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(1), dim3(256), 0, st, ncols, ld, zrow, 0, S, Winv, x);
+}
+
 #endif

@@ -362,18 +362,7 @@ template <typename T> struct Solver final : SolverBase {
 
     // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
     // measured slower: the column reads are uncoalesced across lanes)
-    void launch_backsweep()
-    {
-        const int ncols = D;
-        const int nblk = (ncols + NB - 1) / NB;
-        for (int p = nblk - 1; p >= 0; p--) {
-            const int p0 = p * NB;
-            int g = (p0 + 63) / 64; // 64 columns per workgroup
-            if (g < 1) g = 1;
-            hipLaunchKernelGGL((k_ldlt_backstep<T, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, d_S.p,
-                               d_Winv.p + (size_t)p * NB * NB, d_dxc.p);
-        }
-    }
+    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p); }
 
     void launch_post_reduce()
     {

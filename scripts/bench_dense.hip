@@ -63,7 +63,8 @@ int main(int argc, char **argv)
             }
         }
         CK(hipEventRecord(e1, st));
-        for (int p = nblk - 1; p >= 0; p--) {
+        if (fused) ba_ldlt_backsweep<double, NB>(st, ncols, ld, D, S, Winv, x);
+        else for (int p = nblk - 1; p >= 0; p--) { // one block column per launch
             const int p0 = p * NB;
             int g = (p0 + 63) / 64; if (g < 1) g = 1;
             hipLaunchKernelGGL((k_ldlt_backstep<double, NB>), dim3(g), dim3(256), 0, st, ncols, ld, D, p0, S, Winv + (size_t)p * NB * NB, x);
