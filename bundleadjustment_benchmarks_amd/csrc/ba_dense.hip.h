@@ -168,15 +168,31 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         Wl[c][r] = (T)0;
     }
     __syncthreads();
-    if (Wprev) {
-        // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other
-        // workgroups, except for block column p0 itself, which this step needs now: every panel workgroup applies it to
-        // the diagonal block (in LDS, redundantly) and to its own 64 rows below (in S).
-        ba_update_tile<T, NB, true>(ld, p0 - NB, p0, p0, true, S, Wprev, Ad);
-        __syncthreads();
-        // the update of this workgroup's own 64 rows below is only needed by the GEMM at the very end: waves 1..3 do it
-        // while wave 0 factors the first two sub-panels (see the A1 stage); every later barrier waits for the stores
-        // (s_waitcnt vmcnt(0)), and the GEMM reads them past L1
+    // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other workgroups,
+    // except for block column p0 itself, which this step needs now: every panel workgroup applies it to the diagonal block
+    // (in LDS, redundantly) and to its own 64 rows below (in S).  The diagonal block is updated by 16 x 16 tiles in the
+    // order the factorisation needs them: tile (0, 0) by wave 0 and (1, 0) by wave 1 right here (16 MFMAs each), the other
+    // eight lower tiles by waves 2 and 3 while the first sub-panel is being factored; the 64 rows below during sub-panels
+    // 1 and 2 (every later barrier waits for those stores, and the GEMM at the end reads them past L1).
+    auto tile16 = [&](int ti, int tj) {
+        const int pp = p0 - NB;
+        typename ba_acc<T>::type acc;
+        T a[NB / 4], b[NB / 4];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) {
+            a[kk] = -S[(size_t)(pp + 4 * kk + lk) * ld + p0 + 16 * tj + li]; // A[j][k] = L[j][k]
+            b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * ti + li];   // B[k][i] = Y[i][k]
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) acc = ba_mfma(a[kk], b[kk], acc);
+#pragma unroll
+        for (int v = 0; v < 4; v++) Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li] = acc[v];
+    };
+    if (Wprev && wv < 2) {
+        tile16(wv, 0);
+        ba_wave_lds_sync(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
     BA_STAMP_PRO
     const int rown = p0 + NB + 64 * blk;
@@ -292,14 +308,23 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             }
         } else {
             const int h = wv - 2;
-            if (own_rows && s < 2) { // look-ahead update of the rows below, hidden under A1(0) and A1(1)
+            if (Wprev && s == 0) { // the rest of the diagonal block's look-ahead update, hidden under A1(0)
+                if (h == 0) { tile16(2, 0); tile16(3, 0); tile16(1, 1); tile16(2, 1); }
+                else { tile16(3, 1); tile16(2, 2); tile16(3, 2); tile16(3, 3); }
+            }
+            if (own_rows && (s == 1 || s == 2)) { // look-ahead update of the rows below, hidden under A1(1) and A1(2)
                 // INL: inlined (fastest, but ~250 VGPRs: one workgroup per CU) or out of line (116 VGPRs: two per CU)
-                const int quad = 2 * s + h;
+                const int quad = 2 * (s - 1) + h;
                 if (INL) ba_update_quad<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, quad);
                 else ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, quad);
             }
-            if (s == 2 && h == 0) w_tile(1, 0, 0); // row s-1 of W
-            if (s == 3) w_tile(2, h, h);
+            // rows 1 and 2 of W (the last row with pivots follows the loop): under A1(3); a block with at most 48 pivots has
+            // no fourth sub-panel, its row 1 is built under A1(2)
+            if (s == 2 && h == 0 && nb <= 48) w_tile(1, 0, 0);
+            if (s == 3) {
+                if (h == 0) { w_tile(1, 0, 0); w_tile(2, 0, 0); }
+                else w_tile(2, 1, 1);
+            }
         }
         BA_STAMP_OWN(6);
         __syncthreads();

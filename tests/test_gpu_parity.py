@@ -258,3 +258,24 @@ def test_tiny_problem_and_minimal_sizes(ba, O, gpu_ok):
         s.try_step(0.5)
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-9 * max(np.linalg.norm(st["dx"]), 1e-300)
+
+
+@pytest.mark.parametrize("ncams", [2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 14, 15, 21, 23])
+def test_dense_block_widths(ba, O, gpu_ok, ncams):
+    """The dense LDL^T works in 64-wide block columns of four 16-wide sub-panels; D = 9 N sweeps the width of the last,
+    partial block column (9 N mod 64 = 18, 27, 36, 45, 54, 63, 17, 35, 44, 53, 62, 7, 61, 15) through every sub-panel
+    count and the single / multiple block-column code paths."""
+    p = ba.Problem.synthetic(ncams, 40 * ncams, 160 * ncams, 100 + ncams)
+    po = to_oracle(p)
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(p, ba.CHOLESKY, ba.F64)
+    s.keep_intermediates(True)
+    s.linearize()
+    for lam in (1e-2, 3.0):
+        st = O.step(O.CHOLESKY, po, Jc, Jp, f, lam)
+        s.try_step(lam)
+        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
