@@ -35,7 +35,7 @@ constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
        SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
        SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */ };
-enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_N };
+enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_N };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -247,7 +247,24 @@ template <typename T> struct Solver final : SolverBase {
     int linearize(double *energy, double *diag_max) override
     {
         int rc;
-        HIPCHK(hipEventRecord(ev[EV_T0], st));
+        if ((rc = linearize_enqueue(diag_max != nullptr))) return rc;
+        if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
+        if (diag_max && (rc = allreduce(d_scal.p + SC_DMAX_P, 1, 1))) return rc;
+        if ((rc = fetch_scalars())) return rc;
+        HIPCHK(hipGetLastError());
+        linearize_account();
+        if (energy) *energy = (double)h_scal[SC_ENERGY];
+        if (diag_max) *diag_max = std::max((double)h_scal[SC_DMAX_P], (double)h_scal[SC_DMAX_C]);
+        return BA_OK;
+    }
+
+    // The launches of linearize() without the read-back: the energy lands in the device scalar slot SC_ENERGY, which the
+    // trial kernels do not touch, so a single-shard LM loop enqueues the trial right behind and reads both results with the
+    // one synchronisation of the trial (no host round trip between an accepted step and the next trial).
+    int linearize_enqueue(bool want_dmax)
+    {
+        int rc;
+        HIPCHK(hipEventRecord(ev[EV_L0], st));
         launch_eval(true, cur);
         launch_grad();
         if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
@@ -255,7 +272,7 @@ template <typename T> struct Solver final : SolverBase {
         ba_red_jobs jobs{};
         int nj = 0;
         jobs.j[nj++] = {d_part_e.p, gK, 0, SC_ENERGY};
-        if (diag_max) {
+        if (want_dmax) {
             // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
             T *tmp = d_dxc.p;
             hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V.p, tmp);
@@ -264,17 +281,15 @@ template <typename T> struct Solver final : SolverBase {
             jobs.j[nj++] = {tmp, D, 1, SC_DMAX_C};
         }
         hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p);
-        HIPCHK(hipEventRecord(ev[EV_T1], st));
-        if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
-        if (diag_max && (rc = allreduce(d_scal.p + SC_DMAX_P, 1, 1))) return rc;
-        if ((rc = fetch_scalars())) return rc;
-        HIPCHK(hipGetLastError());
-        tm.linearize_ms += ev_ms(EV_T0, EV_T1);
-        tm.n_linearize++;
-        if (energy) *energy = (double)h_scal[SC_ENERGY];
-        if (diag_max) *diag_max = std::max((double)h_scal[SC_DMAX_P], (double)h_scal[SC_DMAX_C]);
+        HIPCHK(hipEventRecord(ev[EV_L1], st));
         have_step = false;
         return BA_OK;
+    }
+
+    void linearize_account()
+    {
+        tm.linearize_ms += ev_ms(EV_L0, EV_L1);
+        tm.n_linearize++;
     }
 
     void launch_eliminate()
@@ -628,15 +643,23 @@ template <typename T> struct Solver final : SolverBase {
         const T lam_min = (T)lm.lambda_min, lam_max = (T)lm.lambda_max, tol_fun = (T)lm.tol_fun;
         T hist[2] = {0, 0}, energy = 0;
         int fun_evals = 0, iter = 0, trials = 0, status = BA_RUNNING, rc = BA_OK;
-        bool stop = false;
+        bool stop = false, lin_pending = false;
         while (true) {
             iter++;
             if (iter > lm.max_iter) { status = BA_MAX_ITERS; break; }
             if (fun_evals > lm.max_fun_ev) { status = BA_TOO_MANY_FUN_EVALS; break; }
             double e = 0, dmax = 0;
-            if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
+            // after an accepted step of a single-shard run the linearisation is only enqueued; its energy (== the test
+            // energy of that step, evaluated by the same code at the same point) is read back together with the trial
+            const bool lin_async = iter > 1 && world == 1 && use_graph && !keep;
+            if (lin_async) {
+                if ((rc = linearize_enqueue(false))) break;
+            } else {
+                if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
+                energy = (T)e;
+            }
+            lin_pending = lin_async;
             fun_evals++;
-            energy = (T)e;
             if (iter == 1) // :278-280 / Cholesky.h:263-265; MOREQR: 1e-6 * max column norm (BacktrackLevMarqMore.h:272-284)
                 lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
             while (true) {
@@ -644,6 +667,7 @@ template <typename T> struct Solver final : SolverBase {
                 const auto t0 = std::chrono::steady_clock::now();
                 double et = 0, rs = 0, dn = 0;
                 if ((rc = try_step_impl((double)lambda, &et, &rs, &dn, use_graph))) { stop = true; break; }
+                if (lin_pending) { energy = h_scal[SC_ENERGY]; linearize_account(); lin_pending = false; }
                 fun_evals++;
                 const T e_test = (T)et;
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -676,6 +700,9 @@ template <typename T> struct Solver final : SolverBase {
                 if (std::fabs(energy - maxf) < tol_fun * energy) { status = BA_SUCCESS; break; } // before x = xTest (:419-428)
             }
             if ((rc = accept())) break;
+        }
+        if (lin_pending && !rc) { // stopped by max_trials right behind an enqueued linearisation
+            if (!(rc = fetch_scalars())) { energy = h_scal[SC_ENERGY]; linearize_account(); }
         }
         if (lm.verbose && rank == 0) printf("--------------------------------------------------------------------------------\n");
         if (out) {

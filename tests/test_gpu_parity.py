@@ -265,7 +265,8 @@ def test_dense_block_widths(ba, O, gpu_ok, ncams):
     """The dense LDL^T works in 64-wide block columns of four 16-wide sub-panels; D = 9 N sweeps the width of the last,
     partial block column (9 N mod 64 = 18, 27, 36, 45, 54, 63, 17, 35, 44, 53, 62, 7, 61, 15) through every sub-panel
     count and the single / multiple block-column code paths."""
-    p = ba.Problem.synthetic(ncams, 40 * ncams, 160 * ncams, 100 + ncams)
+    npts = 40 * ncams
+    p = ba.Problem.synthetic(ncams, npts, min(4, ncams) * npts, 100 + ncams)
     po = to_oracle(p)
     cam = O.init_cams(po)
     f, e = O.residuals(po, cam, po.pts)
