@@ -159,6 +159,15 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
         fa[it] = S[(size_t)(p0 + min(r, c)) * ld + p0 + max(r, c)]; // mirror the lower triangle
     }
+    // operands of the first look-ahead tiles (see below): requested together with the fill, used behind its barrier
+    T t16a[NB / 4], t16b[NB / 4];
+    if (Wprev && wv < 2) {
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) {
+            t16a[kk] = -S[(size_t)(p0 - NB + 4 * kk + lk) * ld + p0 + li];
+            t16b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * wv + li];
+        }
+    }
     if (tid < NB) { dinv[tid] = (T)0; prog[tid] = 0; }
     typedef typename ba_acc<T>::type acc_t;
 #pragma unroll
@@ -174,15 +183,16 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // order the factorisation needs them: tile (0, 0) by wave 0 and (1, 0) by wave 1 right here (16 MFMAs each), the other
     // eight lower tiles by waves 2 and 3 while the first sub-panel is being factored; the 64 rows below during sub-panels
     // 1 and 2 (every later barrier waits for those stores, and the GEMM at the end reads them past L1).
-    auto tile16 = [&](int ti, int tj) {
+    auto tile16_load = [&](int ti, int tj, T (&a)[NB / 4], T (&b)[NB / 4]) {
         const int pp = p0 - NB;
-        typename ba_acc<T>::type acc;
-        T a[NB / 4], b[NB / 4];
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
             a[kk] = -S[(size_t)(pp + 4 * kk + lk) * ld + p0 + 16 * tj + li]; // A[j][k] = L[j][k]
             b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * ti + li];   // B[k][i] = Y[i][k]
         }
+    };
+    auto tile16_apply = [&](int ti, int tj, const T (&a)[NB / 4], const T (&b)[NB / 4]) {
+        typename ba_acc<T>::type acc;
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li];
 #pragma unroll
@@ -190,8 +200,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int v = 0; v < 4; v++) Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li] = acc[v];
     };
+    auto tile16 = [&](int ti, int tj) {
+        T a[NB / 4], b[NB / 4];
+        tile16_load(ti, tj, a, b);
+        tile16_apply(ti, tj, a, b);
+    };
     if (Wprev && wv < 2) {
-        tile16(wv, 0);
+        tile16_apply(wv, 0, t16a, t16b);
         ba_wave_lds_sync(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
     BA_STAMP_PRO

@@ -118,6 +118,26 @@ int main(int argc, char **argv)
     CK(hipStreamSynchronize(st));
     long long hs[64]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_stamp_acc), sizeof(hs)));
     for (int w = 0; w < 4; w++) printf("classic panel wave %d: preamble %lld\n", w, hs[8 * w + 7]);
+    { // stamps of a fused step in the middle of the factorisation (block column 8) and its duration
+        CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
+        hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+        for (int p = 0; p <= 8 && p < nblk; p++) {
+            const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
+            double *wcur = Wp + (size_t)(p & 1) * ld * NB, *wprev = Wp + (size_t)((p + 1) & 1) * ld * NB;
+            if (p == 0) { hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, wcur, Winv); continue; }
+            const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
+            int nupd = 0;
+            for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
+            if (p == 8) CK(hipEventRecord(f0, st));
+            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+            if (p == 8) CK(hipEventRecord(f1, st));
+        }
+        CK(hipStreamSynchronize(st));
+        float fms = 0; CK(hipEventElapsedTime(&fms, f0, f1));
+        long long hf[64]; CK(hipMemcpyFromSymbol(hf, HIP_SYMBOL(ba_stamp_acc), sizeof(hf)));
+        printf("fused step p=8: %.2f us (event to event); workgroup 0, wave 0: preamble %lld  A1 %lld  A2 %lld  A3 %lld  Wassembly %lld  publish+phaseB %lld  (sum %lld cycles)\n",
+               fms * 1e3, hf[7], hf[0], hf[1], hf[3], hf[4], hf[5], hf[7] + hf[0] + hf[1] + hf[2] + hf[3] + hf[4] + hf[5]);
+    }
 #ifdef BA_STAMP2
     for (int sp = 0; sp < 4; sp++) printf("sub-panel %d, cycles per pivot: publish %.0f  readlane+rcp %.0f  lds-read %.0f  fma+store %.0f\n", sp, hs[32 + 4 * sp] / 16.0, hs[32 + 4 * sp + 1] / 16.0, hs[32 + 4 * sp + 2] / 16.0, hs[32 + 4 * sp + 3] / 16.0);
 #endif
