@@ -160,8 +160,9 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         fa[it] = S[(size_t)(p0 + min(r, c)) * ld + p0 + max(r, c)]; // mirror the lower triangle
     }
     // operands of the first look-ahead tiles (see below): requested together with the fill, used behind its barrier
+    // (only in the one-workgroup-per-CU variant: the 64 registers would push the other one over 256 = one wave per SIMD)
     T t16a[NB / 4], t16b[NB / 4];
-    if (Wprev && wv < 2) {
+    if (INL && Wprev && wv < 2) {
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
             t16a[kk] = -S[(size_t)(p0 - NB + 4 * kk + lk) * ld + p0 + li];
@@ -206,6 +207,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         tile16_apply(ti, tj, a, b);
     };
     if (Wprev && wv < 2) {
+        if (!INL) tile16_load(wv, 0, t16a, t16b);
         tile16_apply(wv, 0, t16a, t16b);
         ba_wave_lds_sync(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
