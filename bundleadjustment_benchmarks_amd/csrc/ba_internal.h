@@ -34,6 +34,10 @@ struct ba_structure {
     std::vector<int> obs_cam, obs_pt; // local (obs_pt is the LOCAL point index), size Kl
     std::vector<int> pt_ptr;          // Ml + 1
     int kmax = 0;                     // max observations per point in this shard
+    // points bucketed by track length for the per-point QR (lanes per point x observations per lane):
+    // <= 32 (8 x 4), <= 64 (16 x 4), <= 128 (32 x 4), <= 256 (64 x 4), <= 1024 (64 x 16)
+    std::vector<int> qr_pts;          // Ml local point indices, bucket by bucket (file order inside a bucket)
+    int qr_bucket_ptr[6] = {0, 0, 0, 0, 0, 0};
     // camera pairs
     int npairs = 0;                   // N (N + 1) / 2, pair id = hi (hi + 1) / 2 + lo
     std::vector<int> pair_hi, pair_lo;

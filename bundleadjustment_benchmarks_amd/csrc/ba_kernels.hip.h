@@ -391,14 +391,16 @@ template <typename T, int LPP> __device__ __forceinline__ T group_sum(T v)
     return v;
 }
 
-template <typename T, int LPP>
-__global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jc,
-                                                 const T *__restrict__ Jp, const T *__restrict__ r, const T *__restrict__ lam, T *__restrict__ rec,
-                                                 T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
+template <typename T, int LPP, int SL> // SL observations per lane: points with up to SL * LPP observations
+__global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict__ pt_list, int Ml, int K, const int *__restrict__ pt_ptr,
+                                                 const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ r,
+                                                 const T *__restrict__ lam, T *__restrict__ rec, T *__restrict__ dinv,
+                                                 T *__restrict__ tvec, T *__restrict__ tri)
 {
-    constexpr int SL = 4; // observations per lane: points with up to 4 * LPP observations
+    // the points of one track-length bucket (pt_list; the host buckets them so that a short track does not occupy the lanes
+    // of the longest one)
     const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
-    const int j = gid < Ml ? gid : Ml - 1; // idle groups shadow the last point (no early exit: shuffles need every lane)
+    const int j = pt_list[gid < npts ? gid : npts - 1]; // idle groups shadow the last point (no early exit: shuffles need every lane)
     const int b = pt_ptr[j], k = pt_ptr[j + 1] - b;
     const T sl = tsqrt(*lam);
     T V[SL][6], Q[SL][6];
@@ -468,14 +470,14 @@ __global__ __launch_bounds__(256) void k_elim_qr(int Ml, int K, const int *__res
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) q1[c] = -group_sum<T, LPP>(q1[c]);
-    if (gid < Ml && lg == 0) {
+    if (gid < npts && lg == 0) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = q1[c]; }
         tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
         tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
     }
     // Z_i = A_i^T Q1_i (9x3), zt_i = Z_i t
-    if (gid < Ml) {
+    if (gid < npts) {
 #pragma unroll
         for (int s = 0; s < SL; s++) {
             if (!ok[s]) continue;

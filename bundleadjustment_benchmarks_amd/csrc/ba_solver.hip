@@ -105,7 +105,7 @@ template <typename T> struct Solver final : SolverBase {
     T tau = (T)0.5; // INLIER_THRESHOLD, src/bundle_adjustment_large.cpp:36
     // structure
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
-        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs;
+        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts;
     // state and work arrays
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri, d_rec0, d_dinv0, d_tvec0, d_tri0,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
@@ -141,7 +141,7 @@ template <typename T> struct Solver final : SolverBase {
         if (gM < 1) gM = 1;
         gB = (int)(((size_t)Ml * 8 + 255) / 256);
         if (gB < 1) gB = 1;
-        if (kind != BA_CHOLESKY && sx.kmax > 256) return BA_ERR_ARG; // more than 256 observations of one point: not supported by k_elim_qr
+        if (kind != BA_CHOLESKY && sx.kmax > 1024) return BA_ERR_ARG; // more than 1024 observations of one point: not supported by k_elim_qr
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipHostMalloc((void **)&h_lam, sizeof(T)));
@@ -150,7 +150,7 @@ template <typename T> struct Solver final : SolverBase {
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
         UP(d_pair_lo, sx.pair_lo); UP(d_ent_r, sx.ent_r); UP(d_ent_c, sx.ent_c); UP(d_chunk_ptr, sx.chunk_ptr);
         UP(d_pair_chunk_ptr, sx.pair_chunk_ptr); UP(d_dchunk_ptr, sx.dchunk_ptr); UP(d_cam_dchunk_ptr, sx.cam_dchunk_ptr);
-        UP(d_cam_obs, sx.cam_obs);
+        UP(d_cam_obs, sx.cam_obs); UP(d_qr_pts, sx.qr_pts);
 #undef UP
         // parameters: bundle_adjustment_large.cpp:81-107 (K00 = -f, R = Rodrigues(omega), distortion (k1 f^2, k2 f^4))
         std::vector<T> cam((size_t)15 * N), pts((size_t)3 * (Ml > 0 ? Ml : 1)), meas((size_t)2 * (Kl > 0 ? Kl : 1));
@@ -306,21 +306,20 @@ template <typename T> struct Solver final : SolverBase {
         }
     }
 
-    // lanes per point: 8 covers points with up to 32 observations, ... 64 up to 256 (beyond: not supported by the
-    // register kernel -- ba_solver_create refuses such a problem for the QR symbols)
-    int lpp() const { return sx.kmax <= 32 ? 8 : sx.kmax <= 64 ? 16 : sx.kmax <= 128 ? 32 : 64; }
-
+    // per-point QR, one launch per non-empty track-length bucket (ba_structure: lanes per point x observations per lane)
     void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri)
     {
-#define BA_QR(L) hipLaunchKernelGGL((k_elim_qr<T, L>), dim3(((size_t)Ml * L + 255) / 256), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jc.p, \
-                                    d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri)
-        if (Ml <= 0) return; // an empty shard owns no points
-        switch (lpp()) {
-        case 8: BA_QR(8); break;
-        case 16: BA_QR(16); break;
-        case 32: BA_QR(32); break;
-        default: BA_QR(64); break;
+#define BA_QR(B, L, SLOTS)                                                                                                       \
+        if (sx.qr_bucket_ptr[B + 1] > sx.qr_bucket_ptr[B]) {                                                                   \
+            const int np_ = sx.qr_bucket_ptr[B + 1] - sx.qr_bucket_ptr[B];                                                       \
+            hipLaunchKernelGGL((k_elim_qr<T, L, SLOTS>), dim3(((size_t)np_ * L + 255) / 256), dim3(256), 0, st, np_,           \
+                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri); \
         }
+        BA_QR(0, 8, 4)
+        BA_QR(1, 16, 4)
+        BA_QR(2, 32, 4)
+        BA_QR(3, 64, 4)
+        BA_QR(4, 64, 16)
 #undef BA_QR
     }
 

@@ -53,6 +53,17 @@ int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int
     for (int j = 0; j <= Ml; j++) s->pt_ptr[j] = gptr[s->p0 + j] - s->o0;
     s->kmax = 0;
     for (int j = 0; j < Ml; j++) s->kmax = std::max(s->kmax, s->pt_ptr[j + 1] - s->pt_ptr[j]);
+    {
+        auto bucket = [](int k) { return k <= 32 ? 0 : k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 3 : 4; };
+        int cnt[5] = {0, 0, 0, 0, 0};
+        for (int j = 0; j < Ml; j++) cnt[bucket(s->pt_ptr[j + 1] - s->pt_ptr[j])]++;
+        s->qr_bucket_ptr[0] = 0;
+        for (int b = 0; b < 5; b++) s->qr_bucket_ptr[b + 1] = s->qr_bucket_ptr[b] + cnt[b];
+        int cur[5];
+        for (int b = 0; b < 5; b++) cur[b] = s->qr_bucket_ptr[b];
+        s->qr_pts.resize(Ml);
+        for (int j = 0; j < Ml; j++) s->qr_pts[cur[bucket(s->pt_ptr[j + 1] - s->pt_ptr[j])]++] = j;
+    }
     for (int i = 0; i < Kl; i++) {
         const int src = s->perm[s->o0 + i];
         s->obs_cam[i] = p->cam_idx[src];

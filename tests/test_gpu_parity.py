@@ -280,3 +280,40 @@ def test_dense_block_widths(ba, O, gpu_ok, ncams):
         assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
+
+
+@pytest.mark.parametrize("kind", [1, 3])
+def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
+    """Per-point QR with tracks of 40 / 100 / 200 / 300 / 700 observations (one bucket of lanes-per-point each, the last
+    one with 16 observations per lane) next to ordinary short tracks; repeated observations of a camera by one point are
+    legal input."""
+    p = ba.Problem.synthetic(12, 200, 800, 77)
+    a = p.arrays()
+    rng = np.random.default_rng(5)
+    cam_idx, pt_idx, meas = list(a["cam_idx"]), list(a["pt_idx"]), [tuple(m) for m in a["meas"].reshape(-1, 2)]
+    for j, want in ((3, 40), (50, 100), (51, 200), (120, 300), (199, 700)):
+        mine = [i for i in range(p.K) if a["pt_idx"][i] == j]
+        for n in range(want - len(mine)):
+            src = mine[n % len(mine)]
+            cam_idx.append(a["cam_idx"][src]); pt_idx.append(j)
+            m = a["meas"].reshape(-1, 2)[src] + rng.normal(0, 0.3, 2)
+            meas.append((m[0], m[1]))
+    order = np.argsort(np.array(pt_idx), kind="stable")
+    cam_idx, pt_idx = np.array(cam_idx, np.int32)[order], np.array(pt_idx, np.int32)[order]
+    meas = np.array(meas, np.float64)[order].ravel()
+    K = len(cam_idx)
+    pl = ba.Problem.from_arrays(p.N, p.M, K, cam_idx, pt_idx, meas, a["cams9"], a["pts"])
+    po = O.Problem(p.N, p.M, K, cam_idx, pt_idx, meas, a["cams9"], a["pts"])
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(pl, kind, ba.F64)
+    s.keep_intermediates(True)
+    eg, _ = s.linearize()
+    assert abs(eg - e) < 1e-12 * e
+    for lam in (1e-3, 2.0):
+        st = O.step(kind, po, Jc, Jp, f, lam)
+        s.try_step(lam)
+        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-10
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
