@@ -126,7 +126,8 @@ typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scal
 /* Replaces the construction of BAFunctor + the LM object (bundle_adjustment_large.cpp:117-131): copies the problem
  * to HBM in SoA layout, builds the static camera-pair structure.  Points (and their observations) are partitioned
  * into shard_world contiguous ranges balanced by observation count; this handle owns range shard_rank.
- * device < 0 keeps the current HIP device. Fails with BA_ERR_HIP when no GPU is present. */
+ * device < 0 keeps the current HIP device. Fails with BA_ERR_HIP when no GPU is present, with BA_ERR_ARG when a QR symbol
+ * meets a point with more than 1024 observations (the per-point QR keeps a track in registers; CHOLESKY has no limit). */
 int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar, int device, int shard_rank,
                      int shard_world, ba_solver **out);
 void ba_solver_free(ba_solver *s);
