@@ -109,7 +109,7 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
 template <typename T, int NB, bool TOLDS>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1]);
-template <typename T, int NB, bool TOLDS>
+template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad);
 template <typename T, int NB>
@@ -131,9 +131,13 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 //   A3  the remaining tiles of the block get the rank-16 update on the matrix cores.
 // W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
 // block need Y = A21 W^T -- a GEMM, also on the matrix cores.
+// flags != nullptr (k_ldlt_step<INL = true>): the look-ahead update of this workgroup's 64 rows below is done by ANOTHER
+// workgroup of the same launch, which then stores `epoch` into flags[row block]; this workgroup waits for it just in front of
+// the row GEMM (the update takes ~6 us, the diagonal block ~20: the wait is a formality, bounded in any case).
 template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
-                                              T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel)
+                                              T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel,
+                                              const int *flags = nullptr, int epoch = 0)
 {
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
@@ -325,15 +329,22 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             }
         } else {
             const int h = wv - 2;
-            if (Wprev && s == 0) { // the rest of the diagonal block's look-ahead update, hidden under A1(0)
-                if (h == 0) { tile16(2, 0); tile16(3, 0); tile16(1, 1); tile16(2, 1); }
-                else { tile16(3, 1); tile16(2, 2); tile16(3, 2); tile16(3, 3); }
-            }
-            if (own_rows && (s == 1 || s == 2)) { // look-ahead update of the rows below, hidden under A1(1) and A1(2)
-                // INL: inlined (fastest, but ~250 VGPRs: one workgroup per CU) or out of line (116 VGPRs: two per CU)
-                const int quad = 2 * (s - 1) + h;
-                if (INL) ba_update_quad<T, NB, false>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, quad);
-                else ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, quad);
+            if (flags) {
+                // The rest of the diagonal block's look-ahead update, at most two tiles per wave and sub-panel (a tile costs
+                // ~2.4 k cycles, a sub-panel ~5 k).  The update is additive, so a tile only has to have it before it is next
+                // READ: column 0 by A2(0), (1,1) by A1(1), column 1 by A2(1), (2,2) by A1(2), (3,2) by A2(2), (3,3) by A1(3).
+                if (Wprev) {
+                    if (s == 0) { if (h == 0) { tile16(2, 0); tile16(3, 0); } else tile16(1, 1); }
+                    if (s == 1) { if (h == 0) { tile16(2, 1); tile16(3, 1); } else { tile16(2, 2); tile16(3, 3); } }
+                    if (s == 2 && h == 0) tile16(3, 2);
+                }
+            } else {
+                if (Wprev && s == 0) { // the rest of the diagonal block's look-ahead update, hidden under A1(0)
+                    if (h == 0) { tile16(2, 0); tile16(3, 0); tile16(1, 1); tile16(2, 1); }
+                    else { tile16(3, 1); tile16(2, 2); tile16(3, 2); tile16(3, 3); }
+                }
+                if (own_rows && (s == 1 || s == 2)) // look-ahead update of the rows below, under A1(1) and A1(2), out of line
+                    ba_update_quad_call<T, NB>(ld, p0 - NB, rown, p0, S, Wprev, 2 * (s - 1) + h);
             }
             // rows 1 and 2 of W (the last row with pivots follows the loop): under A1(3); a block with at most 48 pivots has
             // no fourth sub-panel, its row 1 is built under A1(2)
@@ -415,6 +426,14 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     }
     // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
     const int r0 = p0 + NB + 64 * blk + 16 * wv;
+    if (flags && own_rows) { // the look-ahead update of these rows by another workgroup of this launch (see k_ldlt_step)
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads(); // the rows are read with agent-scope loads below, by every wave behind this barrier
+    }
     if (r0 >= nrows || nb < NB) return;
     acc_t acc[4];
 #pragma unroll
@@ -455,8 +474,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 // Stand-alone panel step (first block column, dense bench).
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
-                                                    T *__restrict__ Winv)
+                                                    T *__restrict__ Winv, int *__restrict__ flags = nullptr, int nflags = 0)
 {
+    if (flags && blockIdx.x == 0) // hand-off flags of the fused steps that follow (k_ldlt_step<INL = true>): cleared per factorisation
+        for (int i = threadIdx.x; i < nflags; i += 256) flags[i] = 0;
     ba_panel_body<T, NB, false>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x);
 }
 
@@ -465,17 +486,34 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 //   workgroups [npanel, gridDim.x): the rest of the trailing update of block column p0 - 64 (tiles with columns >= p0 + 64).
 // The two groups touch disjoint parts of S; Wp is double-buffered (Wprev read, Wp written).  The panel's 2313-long pivot
 // recurrence is the critical path of the factorisation; this hides the MFMA update behind it.
+//
+// INL = true (D <~ 3000: one workgroup per CU, the panel is the critical path): nq further workgroups in FRONT of the grid take
+// the look-ahead update of the panel workgroups' rows (one 64 x 64 tile of block column p0 each, written with agent-scope
+// stores), announce it in flags[row block] and leave; panel workgroup b picks its rows up just before its row GEMM.  They are
+// dispatched before the workgroups that wait for them, so the wait cannot starve them.  INL = false keeps that update
+// inside the panel workgroup (two helper waves, out of line), nq = 0.
 template <typename T, int NB, bool INL>
 __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
-                                                   T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv)
+                                                   T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
+                                                   int nq = 0, int *__restrict__ flags = nullptr)
 {
-    if ((int)blockIdx.x < npanel) {
-        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, blockIdx.x, npanel);
+    int bid = blockIdx.x;
+    if (INL && bid < nq) {
+        const int rown = p0 + NB + 64 * bid;
+        ba_update_quad<T, NB, false, true>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, threadIdx.x >> 6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&flags[rown / NB], p0 / NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (INL) bid -= nq;
+    if (bid < npanel) {
+        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, INL ? flags : nullptr, p0 / NB);
         return;
     }
     // tile u of the set {(ti, tj): 1 <= tj <= ti, tj < ntc}, rows p0 + 64 ti, columns p0 + 64 tj
     const int ntc = (ncols - p0 + 63) / 64;
-    int u = blockIdx.x - npanel, ti = 1;
+    int u = bid - npanel, ti = 1;
     for (;; ti++) {
         const int cnt = min(ti, ntc - 1);
         if (u < cnt) break;
@@ -494,7 +532,8 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
 // 4 columns x 128 contiguous bytes.  Operands come straight from L2 (the panel is a few MB at most); 8 k-steps are in
 // flight at once to cover the L2 latency.  LOWER: skip the strictly upper quadrant (diagonal tiles).
 // TOLDS: the C tile lives in the LDS image Cl[col][row] (64 x 65) instead of S (diagonal block inside the panel step).
-template <typename T, int NB, bool TOLDS>
+// STSC: the results leave with agent-scope (sc1, write-through) stores: another workgroup of the SAME launch reads them.
+template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad)
 {
@@ -542,6 +581,7 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
             for (int v = 0; v < 4; v++) {
                 const int cc = 16 * t + ba_crow<T>(lk, v), rr = 16 * u + li;
                 if (TOLDS) Cl[qc + cc][qr + rr] = acc[t][u][v];
+                else if (STSC) __hip_atomic_store(&S[(size_t)(col0 + cc) * ld + row0 + rr], acc[t][u][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else S[(size_t)(col0 + cc) * ld + row0 + rr] = acc[t][u][v];
             }
 }

@@ -105,7 +105,7 @@ template <typename T> struct Solver final : SolverBase {
     T tau = (T)0.5; // INLIER_THRESHOLD, src/bundle_adjustment_large.cpp:36
     // structure
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
-        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts;
+        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
     // state and work arrays
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri, d_rec0, d_dinv0, d_tvec0, d_tri0,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
@@ -183,6 +183,7 @@ template <typename T> struct Solver final : SolverBase {
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
         AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)2 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
 #undef AL
@@ -350,7 +351,7 @@ template <typename T> struct Solver final : SolverBase {
             const bool fused = nblk >= 24;
             if (p == 0 || !fused) {
                 hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
-                                   fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB);
+                                   fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB, d_flags.p, (int)d_flags.n);
                 const int p1 = p0 + NB;
                 if (!fused && p1 < ncols) {
                     const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
@@ -364,9 +365,11 @@ template <typename T> struct Solver final : SolverBase {
                 // Up to D ~ 3000 the panel is the critical path: the variant with the look-ahead update inlined into the
                 // sub-panel loop (~250 VGPRs, one workgroup per CU, so a panel workgroup never shares its CU with an update
                 // workgroup).  Beyond, the update dominates: out-of-line variant, 116 VGPRs + < 80 KiB LDS = two per CU.
-                if (nblk < 48)
-                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(npanel + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, npanel, d_S.p,
-                                       wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
+                if (nblk < 48) {
+                    const int nq = below > 0 ? npanel : 0; // workgroups that update the panel workgroups' rows (see k_ldlt_step)
+                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + npanel + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, npanel,
+                                       d_S.p, wcur, wprev, d_Winv.p + (size_t)p * NB * NB, nq, d_flags.p);
+                }
                 else
                     hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, d_S.p,
                                    wcur, wprev, d_Winv.p + (size_t)p * NB * NB);

@@ -27,13 +27,14 @@ int main(int argc, char **argv)
         }
     for (int c = 0; c < D; c++) h[(size_t)c * ld + D] = rand() / (double)RAND_MAX; // rhs row
     for (int c = D; c < Dp; c++) h[(size_t)c * ld + c] = 1.0;
-    double *S, *Wp, *Winv, *x, *S0;
+    double *S, *Wp, *Winv, *x, *S0; int *flags;
     long long *stamps;
     CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
     CK(hipMalloc(&Wp, sizeof(double) * (size_t)2 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
     CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     CK(hipMemset(Wp, 0, sizeof(double) * (size_t)2 * ld * NB));
+    const int nflags = Dp / NB + 2; CK(hipMalloc(&flags, sizeof(int) * nflags)); CK(hipMemset(flags, 0, sizeof(int) * nflags));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
     const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
@@ -49,7 +50,7 @@ int main(int argc, char **argv)
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
             double *wcur = Wp + (size_t)(p & 1) * ld * NB, *wprev = Wp + (size_t)((p + 1) & 1) * ld * NB;
             if (p == 0 || !fused) {
-                hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp, Winv + (size_t)p * NB * NB);
+                hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp, Winv + (size_t)p * NB * NB, flags, nflags);
                 const int p1 = p0 + NB;
                 if (!fused && p1 < ncols) {
                     const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
@@ -59,7 +60,7 @@ int main(int argc, char **argv)
                 const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                if (nblk < 48) hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB); else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+                if (nblk < 48) { const int nq = below > 0 ? g : 0; hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(nq + g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB, nq, flags); } else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
             }
         }
         CK(hipEventRecord(e1, st));
@@ -124,12 +125,12 @@ int main(int argc, char **argv)
         for (int p = 0; p <= 8 && p < nblk; p++) {
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
             double *wcur = Wp + (size_t)(p & 1) * ld * NB, *wprev = Wp + (size_t)((p + 1) & 1) * ld * NB;
-            if (p == 0) { hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, wcur, Winv); continue; }
+            if (p == 0) { hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, wcur, Winv, flags, nflags); continue; }
             const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
             int nupd = 0;
             for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
             if (p == 8) CK(hipEventRecord(f0, st));
-            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(2 * g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB, g, flags);
             if (p == 8) CK(hipEventRecord(f1, st));
         }
         CK(hipStreamSynchronize(st));
