@@ -223,7 +223,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // Off-diagonal tile W_ts of W = L11^-1 (t > sc): W_ts = -W_tt sum_{u=sc}^{t-1} L_tu W_us, one wave, MFMA products.
     // Row t only needs rows < t of W, L_tu (final after A2 of sub-panel u) and W_tt (from A1 of sub-panel t), so row t is
     // built by the otherwise idle waves 1..3 while wave 0 runs A1 of sub-panel t + 1; only the last row is exposed.
-    auto w_tile = [&](int t, int sc, int scratch) {
+    // w_sum: Ts[scratch] = sum_u L_tu W_us (needs neither W_tt nor the other tiles of row t); w_fin: W_ts = -W_tt Ts[scratch].
+    auto w_sum = [&](int t, int sc, int scratch) {
         acc_t acc;
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = 0;
@@ -237,6 +238,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int v = 0; v < 4; v++) Ts[scratch][ba_crow<T>(lk, v)][li] = acc[v];
         ba_wave_lds_sync();
+    };
+    auto w_fin = [&](int t, int sc, int scratch) {
         acc_t acc2;
 #pragma unroll
         for (int v = 0; v < 4; v++) acc2[v] = 0;
@@ -250,6 +253,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         for (int v = 0; v < 4; v++) Wl[16 * t + ba_crow<T>(lk, v)][16 * sc + li] = acc2[v];
         ba_wave_lds_sync();
     };
+    auto w_tile = [&](int t, int sc, int scratch) { w_sum(t, sc, scratch); w_fin(t, sc, scratch); };
 #pragma unroll 1
     for (int s = 0; s < 4; s++) {
         const int c0 = 16 * s;
@@ -350,8 +354,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             // no fourth sub-panel, its row 1 is built under A1(2)
             if (s == 2 && h == 0 && nb <= 48) w_tile(1, 0, 0);
             if (s == 3) {
-                if (h == 0) { w_tile(1, 0, 0); w_tile(2, 0, 0); }
-                else w_tile(2, 1, 1);
+                // ... and the sums of row 3, which do not need W_33 (being built by wave 1 right now): only the three
+                // 16 x 16 products W_3c = -W_33 T_c remain behind the loop
+                if (h == 0) { w_tile(1, 0, 0); w_tile(2, 0, 0); w_sum(3, 0, 0); }
+                else { w_tile(2, 1, 1); w_sum(3, 1, 1); w_sum(3, 2, 2); }
             }
         }
         BA_STAMP_OWN(6);
@@ -412,7 +418,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // ---- the last row of W that has pivots (rows before it were built under A1 of the following sub-panels)
     {
         const int tl = (nb - 1) / 16; // last tile row with pivots
-        if (tl >= 1 && wv < tl) w_tile(tl, wv, wv);
+        if (tl == 3) { if (wv < 3) w_fin(3, wv, wv); } // its sums were formed under A1(3) (Ts is not touched in between)
+        else if (tl >= 1 && wv < tl) w_tile(tl, wv, wv);
     }
     __syncthreads();
     BA_STAMP_SEG(4);
