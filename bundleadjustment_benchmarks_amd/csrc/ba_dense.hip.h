@@ -142,13 +142,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
     __shared__ T Wl[NB][NB + 1]; // W[row][col]
-    // Ys (unscaled sub-panel Y[col][row], live in the A2 / A3 phases) and Ts (per-wave scratch of the W tiles, live in
-    // the A1 phases and after the loop) are never live together: they share storage, which keeps the workgroup under
-    // 80 KiB so that two workgroups fit a CU (the trailing-update workgroups of the fused launch inherit the footprint).
-    __shared__ T YsTs[16 * (NB + 1)];
-    T (*Ys)[NB + 1] = reinterpret_cast<T (*)[NB + 1]>(YsTs);
-    T (*Ts)[16][17] = reinterpret_cast<T (*)[16][17]>(YsTs);
-    static_assert(3 * 16 * 17 <= 16 * (NB + 1), "Ts must fit into Ys");
+    // Ys: unscaled sub-panel Y[col][row] (written in A2, read by the rank-16 updates, part of which run under the NEXT pivot
+    // loop); Ts: per-wave scratch of the W tiles, kept in the strictly upper tiles of W's own image, which nobody reads.  ~79 KiB in total: two workgroups still fit a CU (the trailing-update
+    // workgroups of the fused launch inherit the footprint).
+    __shared__ T Ys[16][NB + 1];
+#define BA_TS(sc, r, c) Wl[(r)][16 * ((sc) + 1) + (c)] /* scratch tile sc = the (never read) strictly upper tile (0, sc + 1) of W */
     __shared__ T colx4[4][16], wtile[16][17], dinv[NB], junkbuf[64];
     __shared__ int prog[64]; // A1 hand-off: pivots of the diagonal block whose multipliers are in Ad (per lane)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -236,7 +234,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 acc = ba_mfma(la, wb, acc);
             }
 #pragma unroll
-        for (int v = 0; v < 4; v++) Ts[scratch][ba_crow<T>(lk, v)][li] = acc[v];
+        for (int v = 0; v < 4; v++) BA_TS(scratch, ba_crow<T>(lk, v), li) = acc[v];
         ba_wave_lds_sync();
     };
     auto w_fin = [&](int t, int sc, int scratch) {
@@ -246,7 +244,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const T wa = -Wl[16 * t + li][16 * t + 4 * kk + lk]; // A[i][k] = -W_tt[i][k]
-            const T tb = Ts[scratch][4 * kk + lk][li];           // B[k][j] = T[k][j]
+            const T tb = BA_TS(scratch, 4 * kk + lk, li);        // B[k][j] = T[k][j]
             acc2 = ba_mfma(wa, tb, acc2);
         }
 #pragma unroll
@@ -254,6 +252,22 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         ba_wave_lds_sync();
     };
     auto w_tile = [&](int t, int sc, int scratch) { w_sum(t, sc, scratch); w_fin(t, sc, scratch); };
+    // rank-16 update by the sub-panel at column cs (npv pivots) of tile (ti, tj) counted from the tile behind it:
+    // C^T[j][i] -= sum_k L[j][k] Y[i][k]
+    auto a3_tile = [&](int cs, int npv, int ti, int tj) {
+        const int r0 = cs + 16 + 16 * ti, q0 = cs + 16 + 16 * tj;
+        acc_t acc;
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = Ad[q0 + ba_crow<T>(lk, v)][r0 + li];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const T la = (4 * kk + lk < npv) ? -Ad[cs + 4 * kk + lk][q0 + li] : (T)0; // A[j][k] = L[j][k]
+            const T yb = Ys[4 * kk + lk][r0 + li];                                      // B[k][i] = Y[i][k]
+            acc = ba_mfma(la, yb, acc);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) Ad[q0 + ba_crow<T>(lk, v)][r0 + li] = acc[v];
+    };
 #pragma unroll 1
     for (int s = 0; s < 4; s++) {
         const int c0 = 16 * s;
@@ -333,6 +347,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             }
         } else {
             const int h = wv - 2;
+            if (s >= 1) { // the rank-16 updates by sub-panel s - 1 that wave 0 left behind: diagonal tiles to wave 3, the others to
+                          // wave 2 (the same wave that applies a tile's look-ahead update below: no two waves on one tile)
+                const int ntr = 4 - s;
+                for (int ti = 0; ti < ntr; ti++)
+                    for (int tj = 0; tj <= ti; tj++)
+                        if (ti + tj > 0 && ((ti == tj) ? 1 : 0) == h) a3_tile(16 * (s - 1), 16, ti, tj);
+            }
             if (flags) {
                 // The rest of the diagonal block's look-ahead update, at most two tiles per wave and sub-panel (a tile costs
                 // ~2.4 k cycles, a sub-panel ~5 k).  The update is additive, so a tile only has to have it before it is next
@@ -389,28 +410,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         __syncthreads();
         BA_STAMP_SEG(1);
         BA_STAMP_SEG(2);
-        // ---- A3: rank-16 update of the tiles (ti >= tj > s): C^T[j][i] -= sum_k L[j][k] Y[i][k]
-        {
-            const int nt = 3 - s; // trailing tiles per dimension
-            int cnt = 0;
-            for (int ti = 0; ti < nt; ti++)
-                for (int tj = 0; tj <= ti; tj++, cnt++) {
-                    if ((cnt & 3) != wv) continue;
-                    const int r0 = c0 + 16 + 16 * ti, q0 = c0 + 16 + 16 * tj;
-                    acc_t acc;
-#pragma unroll
-                    for (int v = 0; v < 4; v++) acc[v] = Ad[q0 + ba_crow<T>(lk, v)][r0 + li];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const T la = (4 * kk + lk < np) ? -Ad[c0 + 4 * kk + lk][q0 + li] : (T)0; // A[j][k] = L[j][k]
-                        const T yb = Ys[4 * kk + lk][r0 + li];       // B[k][i] = Y[i][k]
-                        acc = ba_mfma(la, yb, acc);
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; v++) Ad[q0 + ba_crow<T>(lk, v)][r0 + li] = acc[v];
-                }
+        // ---- A3: rank-16 update of the tiles (ti >= tj > s).  Only the next diagonal tile is needed at once: wave 0 does it and
+        // goes straight on to the next pivot loop (no barrier); waves 2 and 3 do the others at the start of that loop's phase
+        // (they are read by A2 / A1 of later sub-panels, i.e. behind the barrier that ends it).
+        if (wv == 0) {
+            a3_tile(c0, np, 0, 0);
+            ba_wave_lds_sync();
         }
-        __syncthreads();
         BA_STAMP_SEG(3);
     }
     __syncthreads();
@@ -477,6 +483,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     BA_STAMP_FLUSH
 }
 
+#undef BA_TS
 
 // Stand-alone panel step (first block column, dense bench).
 template <typename T, int NB>
