@@ -322,7 +322,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 15; k++) { // pivot 15 has no rows below it: W_ss is complete one pivot before wave 0 is
                 if (k < np) { // uniform
 #pragma unroll
                     for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
