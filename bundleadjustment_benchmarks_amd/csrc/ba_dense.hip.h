@@ -290,7 +290,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             ba_wave_lds_sync(); // the multipliers overwrite the tile: every lane has its entries first
             T *const junk = junkbuf + lane; // per-lane scratch slot
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 15; k++) { // pivot 15 has no rows below it in the tile: D(15) is final after pivot 14
                 if (k < np) { // uniform
                     const int kq = k >> 2, kc = k & 3;
                     colx4[q][i] = a[kc];                          // column k is the kc-th register of the lanes with q == kq
