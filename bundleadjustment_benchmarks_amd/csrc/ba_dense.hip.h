@@ -330,10 +330,17 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                     T wk[4]; // row k of W is final since pivot k - 1: fetched before the wait for wave 0
 #pragma unroll
                     for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
-                    // column k of L is in Ad?  (no s_sleep: its 64-cycle granularity is a whole LDS round trip)
-                    while (__hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * s + k + 1) {}
+                    // column k of L is in Ad?  The multiplier is requested right behind the progress word (LDS executes a wave's
+                    // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
+                    // round trip together with the W row above, not three in a row.  (No s_sleep: its 64-cycle granularity is a
+                    // whole LDS round trip.)
+                    int pg;
+                    T lr;
+                    do {
+                        pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } while (pg < 16 * s + k + 1);
                     ba_wave_lds_sync();
-                    const T lr = Ad[c0 + k][c0 + i];
                     const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
 #pragma unroll
                     for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
