@@ -365,10 +365,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // The rest of the diagonal block's look-ahead update, at most two tiles per wave and sub-panel (a tile costs
                 // ~2.4 k cycles, a sub-panel ~5 k).  The update is additive, so a tile only has to have it before it is next
                 // READ: column 0 by A2(0), (1,1) by A1(1), column 1 by A2(1), (2,2) by A1(2), (3,2) by A2(2), (3,3) by A1(3).
+                // (A tile that also receives a deferred rank-16 update in the same phase stays on the wave that applies that.)
                 if (Wprev) {
-                    if (s == 0) { if (h == 0) { tile16(2, 0); tile16(3, 0); } else tile16(1, 1); }
-                    if (s == 1) { if (h == 0) { tile16(2, 1); tile16(3, 1); } else { tile16(2, 2); tile16(3, 3); } }
-                    if (s == 2 && h == 0) tile16(3, 2);
+                    if (s == 0) { if (h == 0) { tile16(2, 0); tile16(3, 0); } else { tile16(1, 1); tile16(2, 1); } }
+                    if (s == 1) { if (h == 0) tile16(3, 1); else tile16(2, 2); }
+                    if (s == 2) { if (h == 0) tile16(3, 2); else tile16(3, 3); }
                 }
             } else {
                 if (Wprev && s == 0) { // the rest of the diagonal block's look-ahead update, hidden under A1(0)
