@@ -5,14 +5,18 @@
 // LDL^T of the whole J^T J + lambda I (src/Eigen_ext/BacktrackLevMarqCholesky.h:156,274-282).  The reduced matrix
 // is 85-100 % block-dense, so it is factored as a dense matrix: right-looking, 64-wide block columns.
 //
-//   k_ldlt_panel   every workgroup factors the 64x64 diagonal block (redundantly: it is the critical path and a
-//                  broadcast would cost a kernel boundary).  The block lives in registers, 4x4 elements per thread in
-//                  a 16x16-cyclic distribution, so the work per pivot stays balanced as the active part shrinks; one
-//                  barrier per pivot; the same row operations applied to I give W = L11^-1.  The rows below then
-//                  need Y = A21 L11^-T = A21 W^T, which is a GEMM: done on the matrix cores.
-//   k_ldlt_update  trailing update S_ij -= (L D)_i L_j^T on the matrix cores (v_mfma_f64_16x16x4_f64 /
-//                  v_mfma_f32_16x16x4_f32) -- the one true contraction of the LM trial.
-//   k_ldlt_backstep backward sweep L^T x = z, one launch per block column, using the stored W (x_p = W_p^T z_p).
+//   k_ldlt_panel    panel step of one block column (first block column, small matrices): every workgroup factors the
+//                   64x64 diagonal block itself (it is the critical path; a broadcast would cost a kernel boundary) in
+//                   four 16-wide sub-panels -- one wave runs the pivot loop of a 16x16 tile in registers, a second one
+//                   builds the tile's inverse one pivot behind, the others do MFMA work beside them (ba_panel_body) --
+//                   and keeps W = L11^-1; the rows below then need Y = A21 W^T, a GEMM on the matrix cores.
+//   k_ldlt_step     fused step with look-ahead: panel of block column p, the previous panel's update of block column p
+//                   (diagonal block inside the panel workgroups, their rows on workgroups of their own) and the rest of
+//                   the previous panel's trailing update, in ONE launch per block column.
+//   k_ldlt_update   stand-alone trailing update S_ij -= (L D)_i L_j^T on the matrix cores (v_mfma_f64_16x16x4_f64 /
+//                   v_mfma_f32_16x16x4_f32) -- the one true contraction of the LM trial.
+//   k_ldlt_backpair backward sweep L^T x = z, two block columns per launch, using the stored W (x_p = W_p^T z_p);
+//   k_ldlt_backstep the same for a single block column.
 //
 // No pivoting, no square roots: D keeps the sign of a pivot, like SimplicialLDLT.  The right-hand side rides along
 // as the extra matrix row `zrow` = D: after the factorisation that row holds D^-1 L^-1 b.
@@ -71,13 +75,6 @@ __device__ long long ba_stamp_acc[8 * 8];
 #define BA_STAMP_FLUSH
 #define BA_STAMP_GET(v)
 #define BA_STAMP_SEG(i)
-#endif
-#ifdef BA_STAMP2
-#define BA_STAMP2_GET(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define BA_STAMP2_SEG(i) { BA_STAMP2_GET(st2_t1); st2_acc[i] += (long long)(st2_t1 - st2_t0); st2_t0 = st2_t1; }
-#else
-#define BA_STAMP2_GET(v)
-#define BA_STAMP2_SEG(i)
 #endif
 
 // LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the

@@ -140,9 +140,6 @@ int main(int argc, char **argv)
                fms * 1e3, hf[7], hf[0], hf[1], hf[3], hf[4], hf[5], hf[7] + hf[0] + hf[1] + hf[2] + hf[3] + hf[4] + hf[5]);
         printf("fused step p=8: own work inside the four A1 phases (before their barriers), waves 0..3: %lld %lld %lld %lld\n", hf[6], hf[14], hf[22], hf[30]);
     }
-#ifdef BA_STAMP2
-    for (int sp = 0; sp < 4; sp++) printf("sub-panel %d, cycles per pivot: publish %.0f  readlane+rcp %.0f  lds-read %.0f  fma+store %.0f\n", sp, hs[32 + 4 * sp] / 16.0, hs[32 + 4 * sp + 1] / 16.0, hs[32 + 4 * sp + 2] / 16.0, hs[32 + 4 * sp + 3] / 16.0);
-#endif
     for (int w = 0; w < 4; w++)
         printf("wave %d cycles: A1 %lld (own work %lld)  A2 %lld  scale %lld  A3 %lld  Wassembly %lld  publish+phaseB %lld\n", w, hs[8 * w], hs[8 * w + 6], hs[8 * w + 1],
                hs[8 * w + 2], hs[8 * w + 3], hs[8 * w + 4], hs[8 * w + 5]);
