@@ -87,6 +87,16 @@ __device__ __forceinline__ void ba_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef BA_SENTINEL_DEFINED
+#define BA_SENTINEL_DEFINED
+// A bit pattern no arithmetic produces (hardware NaNs are canonical): marks "not written yet" in a hand-off buffer.
+template <typename T> __device__ __forceinline__ T ba_sentinel();
+template <> __device__ __forceinline__ double ba_sentinel<double>() { return __hiloint2double(-1, -1); }
+template <> __device__ __forceinline__ float ba_sentinel<float>() { return __int_as_float(-1); }
+__device__ __forceinline__ bool ba_is_sentinel(double v) { return __double2hiint(v) == -1 && __double2loint(v) == -1; }
+__device__ __forceinline__ bool ba_is_sentinel(float v) { return __float_as_int(v) == -1; }
+#endif
+
 __device__ __forceinline__ double ba_readlane(double v, int lane)
 {
     union { double d; int i[2]; } u;
@@ -779,9 +789,115 @@ __global__ __launch_bounds__(256) void k_ldlt_backpair(int ncols, int ld, int zr
     }
 }
 
-// Host side of the backward sweep on `st`: pairs of block columns from the bottom, a single block column left over at the top.
+// Backward sweep as ONE launch (data flow between workgroups instead of a launch per step: a back-sweep launch is ~3.5 us of
+// kernel boundary around ~3 us of work).  Workgroup g owns a group of two block columns (the first group is a single
+// block column when their number is odd).  It eliminates the later groups from its right-hand side as their unknowns
+// appear -- each x(i) is an 8-byte granule that its owner publishes with an agent-scope (write-through) store over a
+// sentinel, so a consumer polls the very datum it needs and no flag or ordering is involved -- with the 128 x 128 block of
+// L for the next group already in registers; then it solves its own group like k_ldlt_backpair and publishes.  The chain is
+// one hop per group: poll, 64 FMAs per thread, three LDS GEMV phases.  All groups must be resident at once (19 workgroups
+// at config 4, 72 at config 5; the spins are bounded anyway).  x must hold the sentinel on entry (k_post_reduce /
+// k_fill_sentinel).
+template <typename T>
+__global__ void k_fill_sentinel(int n, T *__restrict__ x)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = ba_sentinel<T>();
+}
+
 template <typename T, int NB>
-inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x)
+__global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zrow, int nblk, T *__restrict__ S, const T *__restrict__ Winv,
+                                                       T *__restrict__ x)
+{
+    static_assert(NB == 64, "written for 64-wide block columns");
+    __shared__ T zs[2 * NB], xin[2 * NB], xs[2 * NB], part[4][NB], part2[2][2 * NB];
+    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    const bool odd = (nblk & 1) != 0;
+    const int fb = odd ? max(0, 2 * g - 1) : 2 * g, nbg = (odd && g == 0) ? 1 : 2; // first block column / block columns of this group
+    const int c0 = fb * NB, ncg = nbg * NB;
+    // operands of the group's own solve: thread (j, q) holds 16 rows of column j of W1, W0 and L10
+    const int j = tid & 63, q = tid >> 6;
+    const T *W0 = Winv + (size_t)fb * NB * NB, *W1 = W0 + (size_t)NB * NB;
+    T w1[16], w0[16], l10[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int k = 16 * q + t;
+        w0[t] = W0[k * NB + j];
+        w1[t] = nbg == 2 ? W1[k * NB + j] : (T)0;
+        l10[t] = nbg == 2 ? S[(size_t)(c0 + j) * ld + c0 + NB + k] : (T)0; // L(c0 + 64 + k, c0 + j)
+    }
+    if (tid < 2 * NB) zs[tid] = (tid < ncg && c0 + tid < ncols) ? S[(size_t)(c0 + tid) * ld + zrow] : (T)0;
+    // elimination of the later groups: thread (j2, h) sums half h of the 128 rows of column j2
+    const int j2 = tid & 127, h = tid >> 7;
+    T lpre[NB];
+    auto load_L = [&](int qg) {
+        const int r0 = (odd ? 2 * qg - 1 : 2 * qg) * NB + NB * h; // (qg >= 1: two block columns)
+        const T *col = S + (size_t)(c0 + (j2 < ncg ? j2 : 0)) * ld + r0;
+#pragma unroll
+        for (int t = 0; t < NB; t++) lpre[t] = col[t];
+    };
+    if (G - 1 > g) load_L(G - 1);
+    __syncthreads();
+    for (int qg = G - 1; qg > g; qg--) {
+        const int r0 = (odd ? 2 * qg - 1 : 2 * qg) * NB;
+        if (tid < 2 * NB) {
+            T xv = (T)0;
+            if (r0 + tid < ncols) {
+                int spins = 0;
+                do xv = __hip_atomic_load(&x[r0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (ba_is_sentinel(xv) && ++spins < (1 << 24));
+            }
+            xin[tid] = xv;
+        }
+        __syncthreads();
+        T a = 0;
+#pragma unroll
+        for (int t = 0; t < NB; t++) a += lpre[t] * xin[NB * h + t];
+        part2[h][j2] = a;
+        if (qg - 1 > g) load_L(qg - 1); // the next group's block is in flight while this one is reduced and the next x awaited
+        __syncthreads();
+        if (tid < 2 * NB) zs[tid] -= part2[0][tid] + part2[1][tid];
+        __syncthreads();
+    }
+    // the group's own unknowns: x1 = W1^T z1;  z0 -= L10^T x1;  x0 = W0^T z0
+    T a = 0;
+    if (nbg == 2) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) a += w1[t] * zs[NB + 16 * q + t];
+        part[q][j] = a;
+        __syncthreads();
+        if (tid < NB) xs[NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        __syncthreads();
+        a = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) a += l10[t] * xs[NB + 16 * q + t];
+        part[q][j] = a;
+        __syncthreads();
+        if (tid < NB) zs[tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        __syncthreads();
+    }
+    a = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) a += w0[t] * zs[16 * q + t];
+    part[q][j] = a;
+    __syncthreads();
+    if (tid < NB) xs[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    __syncthreads();
+    if (tid < ncg && c0 + tid < ncols) __hip_atomic_store(&x[c0 + tid], xs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Host side of the backward sweep on `st`.  armed: x already holds the sentinel (the solver's k_post_reduce does that).
+template <typename T, int NB>
+inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false)
+{
+    const int nblk = (ncols + NB - 1) / NB;
+    if (!armed) hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
+    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3((nblk + 1) / 2), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x);
+}
+
+// The same with one launch per pair of block columns (k_ldlt_backpair): no workgroup waits for another.
+template <typename T, int NB>
+inline void ba_ldlt_backsweep_launches(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x)
 {
     const int nblk = (ncols + NB - 1) / NB;
     int p = nblk - 1;

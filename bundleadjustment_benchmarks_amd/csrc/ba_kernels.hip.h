@@ -22,6 +22,16 @@ __device__ __forceinline__ double tsin(double x) { return sin(x); }
 __device__ __forceinline__ float tsin(float x) { return sinf(x); }
 __device__ __forceinline__ double tcos(double x) { return cos(x); }
 __device__ __forceinline__ float tcos(float x) { return cosf(x); }
+#ifndef BA_SENTINEL_DEFINED
+#define BA_SENTINEL_DEFINED
+// A bit pattern no arithmetic produces (hardware NaNs are canonical): marks "not written yet" in a hand-off buffer.
+template <typename T> __device__ __forceinline__ T ba_sentinel();
+template <> __device__ __forceinline__ double ba_sentinel<double>() { return __hiloint2double(-1, -1); }
+template <> __device__ __forceinline__ float ba_sentinel<float>() { return __int_as_float(-1); }
+__device__ __forceinline__ bool ba_is_sentinel(double v) { return __double2hiint(v) == -1 && __double2loint(v) == -1; }
+__device__ __forceinline__ bool ba_is_sentinel(float v) { return __float_as_int(v) == -1; }
+#endif
+
 template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
 
 // ---- block reductions (fixed order: shuffle tree inside a wave, then waves in index order) -----------------
@@ -645,13 +655,16 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld,
 }
 
 // After the (optional) all-reduce: add lambda to the diagonal, copy the summed g_c out of row D+1, clear the
-// augmented rows D+1.. and give the padding a unit diagonal so that the blocked LDL^T can run over whole tiles.
+// augmented rows D+1.. and give the padding a unit diagonal so that the blocked LDL^T can run over whole tiles; arm the
+// solution vector with the hand-off sentinel.
 template <typename T>
-__global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, const T *__restrict__ lam, T *__restrict__ S, T *__restrict__ gc_out)
+__global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, const T *__restrict__ lam, T *__restrict__ S, T *__restrict__ gc_out,
+                                                     T *__restrict__ xarm)
 {
     const T lambda = *lam;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Dp) return;
+    xarm[c] = ba_sentinel<T>(); // the solution vector of the backward sweep (k_ldlt_backflow polls it entry by entry)
     T *col = S + (size_t)c * ld;
     if (c < D) {
         col[c] += lambda;

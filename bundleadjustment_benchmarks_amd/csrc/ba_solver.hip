@@ -379,11 +379,11 @@ template <typename T> struct Solver final : SolverBase {
 
     // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
     // measured slower: the column reads are uncoalesced across lanes)
-    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p); }
+    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true); }
 
     void launch_post_reduce()
     {
-        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p);
+        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p, d_dxc.p);
     }
 
     int set_lambda(T lambda)
