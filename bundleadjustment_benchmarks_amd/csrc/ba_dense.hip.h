@@ -15,8 +15,8 @@
 //                   the previous panel's trailing update, in ONE launch per block column.
 //   k_ldlt_update   stand-alone trailing update S_ij -= (L D)_i L_j^T on the matrix cores (v_mfma_f64_16x16x4_f64 /
 //                   v_mfma_f32_16x16x4_f32) -- the one true contraction of the LM trial.
-//   k_ldlt_backpair backward sweep L^T x = z, two block columns per launch, using the stored W (x_p = W_p^T z_p);
-//   k_ldlt_backstep the same for a single block column.
+//   k_ldlt_backflow backward sweep L^T x = z in one launch (data flow between workgroups), using the stored W (x_p = W_p^T z_p);
+//   k_ldlt_backpair / k_ldlt_backstep: the same with a launch per two / one block column(s).
 //
 // No pivoting, no square roots: D keeps the sign of a pivot, like SimplicialLDLT.  The right-hand side rides along
 // as the extra matrix row `zrow` = D: after the factorisation that row holds D^-1 L^-1 b.
