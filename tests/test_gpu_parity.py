@@ -317,3 +317,39 @@ def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
         assert relmax(s.get(ba.GET_S), st["S"]) < 1e-10
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
+
+
+@pytest.mark.parametrize("ncams,with_oracle_step", [(180, True), (340, False)])
+def test_fused_factor_paths(ba, O, gpu_ok, ncams, with_oracle_step):
+    """The dense LDL^T switches kernels with the size of the reduced system: below 24 block columns a launch per panel and
+    per update; from D = 9 N >= 1473 the fused look-ahead step with row workgroups and hand-off flags (one workgroup per CU;
+    N = 180: 26 block columns), from 48 block columns the two-workgroups-per-CU variant (N = 340: 48 block columns).  The
+    backward sweep is the one-launch data-flow kernel in every case.  N = 180 is compared with the oracle's step; for
+    N = 340 (a 9 GFLOP factorisation on one CPU core) the backward error of the step in the normal equations is checked."""
+    npts = 12 * ncams
+    p = ba.Problem.synthetic(ncams, npts, 5 * npts, 4000 + ncams)
+    po = to_oracle(p)
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(p, ba.CHOLESKY, ba.F64)
+    s.keep_intermediates(True)
+    eg, _ = s.linearize()
+    assert abs(eg - e) < 1e-12 * e
+    lam = 1e-2
+    s.try_step(lam)
+    dx = s.get(ba.GET_DX)
+    M, N = po.M, po.N
+    Jdx = np.einsum("krc,kc->kr", Jc, dx[3 * M:].reshape(N, 9)[po.cam_idx]) + \
+        np.einsum("krc,kc->kr", Jp, dx[:3 * M].reshape(M, 3)[po.pt_idx])
+    JtJdx = np.zeros_like(dx)
+    np.add.at(JtJdx[3 * M:].reshape(N, 9), po.cam_idx, np.einsum("krc,kr->kc", Jc, Jdx))
+    np.add.at(JtJdx[:3 * M].reshape(M, 3), po.pt_idx, np.einsum("krc,kr->kc", Jp, Jdx))
+    g = np.zeros_like(dx)
+    np.add.at(g[3 * M:].reshape(N, 9), po.cam_idx, -np.einsum("krc,kr->kc", Jc, f.reshape(-1, 2)))
+    np.add.at(g[:3 * M].reshape(M, 3), po.pt_idx, -np.einsum("krc,kr->kc", Jp, f.reshape(-1, 2)))
+    assert np.linalg.norm(JtJdx + lam * dx - g) < 1e-9 * np.linalg.norm(g)
+    if with_oracle_step:
+        st = O.step(O.CHOLESKY, po, Jc, Jp, f, lam)
+        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
+        assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
