@@ -346,9 +346,9 @@ template <typename T> struct Solver final : SolverBase {
             const int below = nrows - (p0 + NB);
             const int npanel = below > 0 ? (below + 63) / 64 : 1;
             T *wcur = d_Wp.p + (size_t)(p & 1) * wsz, *wprev = d_Wp.p + (size_t)((p + 1) & 1) * wsz;
-            // Look-ahead pays once the trailing update is big enough to be worth hiding (measured: D >= ~2000); for small
-            // matrices the panel's extra update work costs more than the saved launch.
-            const bool fused = nblk >= 24;
+            // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
+            // and keeps the previous panel's update off the diagonal block's path.
+            const bool fused = nblk >= 2;
             if (p == 0 || !fused) {
                 hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
                                    fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB, d_flags.p, (int)d_flags.n);
