@@ -35,7 +35,7 @@ constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
        SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
        SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */ };
-enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_N };
+enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_L0B, EV_L1B /* linearisation, one pair per buffer */, EV_F, EV_N };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -107,11 +107,15 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
     // state and work arrays
-    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri, d_rec0, d_dinv0, d_tvec0, d_tri0,
+    // linearisation (r, J, J^T r, block diagonals, MOREQR's outer factors): one set per parameter buffer, so that the
+    // linearisation at xTest can be enqueued while the trial that produced xTest is still being judged on the host
+    DevBuf<T> d_r[2], d_Jc[2], d_Jp[2], d_JcA[2], d_U0[2], d_gp[2], d_V[2], d_gc[2], d_rec0[2], d_dinv0[2], d_tvec0[2], d_tri0[2];
+    DevBuf<T> d_cam[2], d_pts[2], d_meas, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
     T h_scal[NSCAL];
     T *h_lam = nullptr;                      // pinned staging word for lambda
+    T *h_pin = nullptr;                      // pinned landing area of the device scalars (speculating trials)
     hipGraphExec_t gexec[2] = {nullptr, nullptr}; // captured trial, one per parity of the parameter double buffer
     bool use_graph = true;
     hipEvent_t ev[EV_N] = {};
@@ -125,6 +129,7 @@ template <typename T> struct Solver final : SolverBase {
         for (auto &g : gexec)
             if (g) (void)hipGraphExecDestroy(g);
         if (h_lam) (void)hipHostFree(h_lam);
+        if (h_pin) (void)hipHostFree(h_pin);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
 
@@ -145,6 +150,7 @@ template <typename T> struct Solver final : SolverBase {
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipHostMalloc((void **)&h_lam, sizeof(T)));
+        HIPCHK(hipHostMalloc((void **)&h_pin, sizeof(T) * NSCAL));
         use_graph = getenv("BA_NO_GRAPH") == nullptr;
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
@@ -177,10 +183,13 @@ template <typename T> struct Solver final : SolverBase {
             return rc;
         const size_t K1 = Kl > 0 ? Kl : 1, M1 = Ml > 0 ? Ml : 1;
 #define AL(buf, n) if ((rc = buf.alloc(n))) return rc
-        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1); AL(d_V, (size_t)81 * N);
-        AL(d_gc, (size_t)D); AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
+        for (int w = 0; w < 2; w++) {
+            AL(d_r[w], 2 * K1); AL(d_Jc[w], 18 * K1); AL(d_JcA[w], 20 * K1); AL(d_Jp[w], 6 * K1); AL(d_U0[w], 6 * M1); AL(d_gp[w], 3 * M1);
+            AL(d_V[w], (size_t)81 * N); AL(d_gc[w], (size_t)D);
+            if (kind == BA_MOREQR) { AL(d_rec0[w], (size_t)BA_REC * K1); AL(d_dinv0[w], 3 * M1); AL(d_tvec0[w], 3 * M1); AL(d_tri0[w], 6 * M1); }
+        }
+        AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
-        if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
         AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)2 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
@@ -227,21 +236,21 @@ template <typename T> struct Solver final : SolverBase {
         const T tau2 = tau * tau;
         if (jac)
             hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r[which].p, d_Jc[which].p, d_Jp[which].p, d_JcA[which].p, d_part_e.p);
         else
             hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
                                d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p);
     }
 
-    void launch_grad()
+    void launch_grad(int which)
     {
-        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p,
+        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp[which].p, d_r[which].p, d_U0[which].p, d_gp[which].p,
                            d_part_pm.p);
         if (sx.ndchunks > 0)
             hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
-                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p);
+                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA[which].p, d_dslab.p);
         hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
-                           d_dslab.p, d_V.p, d_gc.p);
+                           d_dslab.p, d_V[which].p, d_gc[which].p);
     }
 
     // m_functor(x, r); energy; m_functor.df(x, J); JtRes; column norms (BacktrackLevMarqQRChol.h:257-280)
@@ -262,59 +271,63 @@ template <typename T> struct Solver final : SolverBase {
     // The launches of linearize() without the read-back: the energy lands in the device scalar slot SC_ENERGY, which the
     // trial kernels do not touch, so a single-shard LM loop enqueues the trial right behind and reads both results with the
     // one synchronisation of the trial (no host round trip between an accepted step and the next trial).
-    int linearize_enqueue(bool want_dmax)
+    // which: the parameter buffer to linearise at -- cur, or 1 - cur = xTest of the trial just enqueued (speculation on its
+    // acceptance: the set of linearisation arrays of the other buffer is written, the current one stays intact for a retry).
+    int linearize_enqueue(bool want_dmax, int which = -1)
     {
         int rc;
-        HIPCHK(hipEventRecord(ev[EV_L0], st));
-        launch_eval(true, cur);
-        launch_grad();
+        const bool speculative = which >= 0 && which != cur;
+        if (which < 0) which = cur;
+        HIPCHK(hipEventRecord(ev[EV_L0 + 2 * which], st));
+        launch_eval(true, which);
+        launch_grad(which);
         if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
-            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p);
+            launch_elim_qr(which, d_scal.p + SC_ZERO, d_rec0[which].p, d_dinv0[which].p, d_tvec0[which].p, d_tri0[which].p);
         ba_red_jobs jobs{};
         int nj = 0;
         jobs.j[nj++] = {d_part_e.p, gK, 0, SC_ENERGY};
         if (want_dmax) {
             // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
             T *tmp = d_dxc.p;
-            hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V.p, tmp);
+            hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V[which].p, tmp);
             if ((rc = allreduce(tmp, (size_t)D, 0))) return rc;
             jobs.j[nj++] = {d_part_pm.p, gM, 1, SC_DMAX_P};
             jobs.j[nj++] = {tmp, D, 1, SC_DMAX_C};
         }
         hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p);
-        HIPCHK(hipEventRecord(ev[EV_L1], st));
-        have_step = false;
+        HIPCHK(hipEventRecord(ev[EV_L1 + 2 * which], st));
+        if (!speculative) have_step = false;
         return BA_OK;
     }
 
-    void linearize_account()
+    void linearize_account() // of the linearisation at the current buffer (its events are complete: its results have been used)
     {
-        tm.linearize_ms += ev_ms(EV_L0, EV_L1);
+        tm.linearize_ms += ev_ms(EV_L0 + 2 * cur, EV_L1 + 2 * cur);
         tm.n_linearize++;
     }
 
     void launch_eliminate()
     {
         if (kind == BA_CHOLESKY) {
-            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
-                               d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc[cur].p, d_Jp[cur].p,
+                               d_U0[cur].p, d_gp[cur].p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else if (kind == BA_MOREQR) {
             if (Kl > 0) // BacktrackLevMarqMore.h:297-345, the per-trial QR of [R ; sqrt(lambda) I]
                 hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
-                                   d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+                                   d_rec0[cur].p, d_tri0[cur].p, d_tvec0[cur].p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+            launch_elim_qr(cur, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         }
     }
 
     // per-point QR, one launch per non-empty track-length bucket (ba_structure: lanes per point x observations per lane)
-    void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri)
+    void launch_elim_qr(int which, const T *lam, T *rec, T *dinv, T *tvec, T *tri)
     {
 #define BA_QR(B, L, SLOTS)                                                                                                       \
         if (sx.qr_bucket_ptr[B + 1] > sx.qr_bucket_ptr[B]) {                                                                   \
             const int np_ = sx.qr_bucket_ptr[B + 1] - sx.qr_bucket_ptr[B];                                                       \
             hipLaunchKernelGGL((k_elim_qr<T, L, SLOTS>), dim3(((size_t)np_ * L + 255) / 256), dim3(256), 0, st, np_,           \
-                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri); \
+                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc[which].p, d_Jp[which].p, d_r[which].p, lam, rec, dinv, tvec, tri); \
         }
         BA_QR(0, 8, 4)
         BA_QR(1, 16, 4)
@@ -331,7 +344,7 @@ template <typename T> struct Solver final : SolverBase {
                                d_chunk_ptr.p, d_ent_r.p, d_ent_c.p, d_rec.p, d_slab.p);
         const long long nthr = (long long)sx.npairs * BA_SLAB;
         hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, sx.npairs, D, ld,
-                           d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);
+                           d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V[cur].p, d_gc[cur].p, d_S.p);
     }
 
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
@@ -397,7 +410,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (Ml > 0) // (an empty shard keeps the zero partial sums written at creation)
         hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
-                           d_tri.p, d_dxc.p, d_gp.p, d_pts[cur].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
+                           d_tri.p, d_dxc.p, d_gp[cur].p, d_pts[cur].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
         hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
                            d_cam[1 - cur].p, d_scal.p, (int)SC_RHO_C);
     }
@@ -421,7 +434,10 @@ template <typename T> struct Solver final : SolverBase {
     // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375)
     // graph = true (used by minimize on a single shard): the ~110 launches of a trial are captured once per parameter
     // buffer parity into a hipGraph and replayed; lambda reaches the kernels through device memory.
-    int try_step_impl(double lambda_d, double *e_test, double *rho_scale, double *dx_norm, bool graph)
+    // speculate (minimize, single shard, replayed trials): the linearisation at xTest is enqueued right behind the trial, in
+    // front of the wait for its scalars -- the GPU forms it while the host judges the step and launches the next trial; a
+    // rejected step simply leaves it unused (it lives in the other buffer's set of arrays).
+    int try_step_impl(double lambda_d, double *e_test, double *rho_scale, double *dx_norm, bool graph, bool speculate = false)
     {
         int rc;
         if ((rc = set_lambda((T)lambda_d))) return rc;
@@ -437,7 +453,13 @@ template <typename T> struct Solver final : SolverBase {
             HIPCHK(hipEventRecord(ev[EV_T0], st));
             HIPCHK(hipGraphLaunch(gexec[cur], st));
             HIPCHK(hipEventRecord(ev[EV_T6], st));
-            if ((rc = fetch_scalars())) return rc;
+            if (speculate) {
+                HIPCHK(hipMemcpyAsync(h_pin, d_scal.p, sizeof(T) * NSCAL, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipEventRecord(ev[EV_F], st));
+                if ((rc = linearize_enqueue(false, 1 - cur))) return rc;
+                HIPCHK(hipEventSynchronize(ev[EV_F]));
+                for (int i = 0; i < NSCAL; i++) h_scal[i] = h_pin[i];
+            } else if ((rc = fetch_scalars())) return rc;
             HIPCHK(hipGetLastError());
             tm.trial_ms += ev_ms(EV_T0, EV_T6);
             tm.n_graph_trials++;
@@ -539,28 +561,28 @@ template <typename T> struct Solver final : SolverBase {
         switch (what) {
         case BA_GET_RESIDUALS: {
             if (n != 2 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_r.p, 2 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_r[cur].p, 2 * (size_t)Kl, h))) return rc;
             // file order inside the shard when the input was sorted; sorted order otherwise (perm documents it)
             for (int i = 0; i < Kl; i++) { out[2 * (size_t)i] = h[i]; out[2 * (size_t)i + 1] = h[(size_t)Kl + i]; }
             return BA_OK;
         }
         case BA_GET_JC: {
             if (n != 18 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_Jc.p, 18 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_Jc[cur].p, 18 * (size_t)Kl, h))) return rc;
             for (int i = 0; i < Kl; i++)
                 for (int q = 0; q < 18; q++) out[18 * (size_t)i + q] = h[(size_t)q * Kl + i];
             return BA_OK;
         }
         case BA_GET_JP: {
             if (n != 6 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_Jp.p, 6 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_Jp[cur].p, 6 * (size_t)Kl, h))) return rc;
             for (int i = 0; i < Kl; i++)
                 for (int q = 0; q < 6; q++) out[6 * (size_t)i + q] = h[(size_t)q * Kl + i];
             return BA_OK;
         }
         case BA_GET_GRAD: {
             if (n != 3 * (size_t)Ml + D) return BA_ERR_ARG;
-            if ((rc = dl(d_gp.p, 3 * (size_t)Ml, h)) || (rc = dl(d_gc.p, D, h2))) return rc;
+            if ((rc = dl(d_gp[cur].p, 3 * (size_t)Ml, h)) || (rc = dl(d_gc[cur].p, D, h2))) return rc;
             for (int j = 0; j < Ml; j++)
                 for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
             for (int c = 0; c < D; c++) out[3 * (size_t)Ml + c] = h2[c];
@@ -651,11 +673,12 @@ template <typename T> struct Solver final : SolverBase {
             if (iter > lm.max_iter) { status = BA_MAX_ITERS; break; }
             if (fun_evals > lm.max_fun_ev) { status = BA_TOO_MANY_FUN_EVALS; break; }
             double e = 0, dmax = 0;
-            // after an accepted step of a single-shard run the linearisation is only enqueued; its energy (== the test
-            // energy of that step, evaluated by the same code at the same point) is read back together with the trial
+            // after an accepted step of a single-shard run the linearisation is already in the stream (try_step_impl, speculate);
+            // its energy (== the test energy of that step, evaluated by the same code at the same point) is read back together
+            // with the next trial
             const bool lin_async = iter > 1 && world == 1 && use_graph && !keep;
             if (lin_async) {
-                if ((rc = linearize_enqueue(false))) break;
+                // (already enqueued behind the accepted trial, speculatively, for the buffer that is now the current one)
             } else {
                 if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
                 energy = (T)e;
@@ -668,7 +691,7 @@ template <typename T> struct Solver final : SolverBase {
                 if (lm.max_trials > 0 && trials >= lm.max_trials) { stop = true; status = BA_RUNNING; break; }
                 const auto t0 = std::chrono::steady_clock::now();
                 double et = 0, rs = 0, dn = 0;
-                if ((rc = try_step_impl((double)lambda, &et, &rs, &dn, use_graph))) { stop = true; break; }
+                if ((rc = try_step_impl((double)lambda, &et, &rs, &dn, use_graph, world == 1 && use_graph && !keep))) { stop = true; break; }
                 if (lin_pending) { energy = h_scal[SC_ENERGY]; linearize_account(); lin_pending = false; }
                 fun_evals++;
                 const T e_test = (T)et;
@@ -733,7 +756,7 @@ template <typename T> struct Solver final : SolverBase {
         for (int k = 0; k < reps; k++) {
             switch (phase) {
             case 0: launch_eval(false, cur); break;
-            case 1: launch_eval(true, cur); launch_grad(); break;
+            case 1: launch_eval(true, cur); launch_grad(cur); break;
             case 2: launch_eliminate(); break;
             case 3: launch_schur(); break;
             case 4:
