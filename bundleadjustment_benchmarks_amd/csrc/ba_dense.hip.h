@@ -887,12 +887,17 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 }
 
 // Host side of the backward sweep on `st`.  armed: x already holds the sentinel (the solver's k_post_reduce does that).
+template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x);
+
+// max_groups: how many workgroups of k_ldlt_backflow are certainly resident at once (one per CU is a safe count; they
+// wait for each other, so a grid beyond that falls back to a launch per pair of block columns).
 template <typename T, int NB>
-inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false)
+inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false, int max_groups = 256)
 {
-    const int nblk = (ncols + NB - 1) / NB;
+    const int nblk = (ncols + NB - 1) / NB, groups = (nblk + 1) / 2;
+    if (groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
     if (!armed) hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
-    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3((nblk + 1) / 2), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x);
+    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x);
 }
 
 // The same with one launch per pair of block columns (k_ldlt_backpair): no workgroup waits for another.

@@ -121,6 +121,7 @@ template <typename T> struct Solver final : SolverBase {
     hipEvent_t ev[EV_N] = {};
     int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
     bool have_step = false;
+    int num_cus = 256; // of the device the solver lives on
 
     ~Solver() override
     {
@@ -152,6 +153,12 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipHostMalloc((void **)&h_lam, sizeof(T)));
         HIPCHK(hipHostMalloc((void **)&h_pin, sizeof(T) * NSCAL));
         use_graph = getenv("BA_NO_GRAPH") == nullptr;
+        {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                num_cus = pr.multiProcessorCount;
+        }
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
         UP(d_pair_lo, sx.pair_lo); UP(d_ent_r, sx.ent_r); UP(d_ent_c, sx.ent_c); UP(d_chunk_ptr, sx.chunk_ptr);
@@ -392,7 +399,7 @@ template <typename T> struct Solver final : SolverBase {
 
     // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
     // measured slower: the column reads are uncoalesced across lanes)
-    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true); }
+    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true, num_cus); }
 
     void launch_post_reduce()
     {
