@@ -661,17 +661,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, const T *__restrict__ lam, T *__restrict__ S, T *__restrict__ gc_out,
                                                      T *__restrict__ xarm)
 {
-    const T lambda = *lam;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // one wave per column, lane = row offset: the cleared rows of a column are contiguous (coalesced stores)
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= Dp) return;
-    xarm[c] = ba_sentinel<T>(); // the solution vector of the backward sweep (k_ldlt_backflow polls it entry by entry)
     T *col = S + (size_t)c * ld;
+    if (lane == 0) xarm[c] = ba_sentinel<T>(); // the solution vector of the backward sweep (k_ldlt_backflow polls it entry by entry)
     if (c < D) {
-        col[c] += lambda;
-        gc_out[c] = col[D + 1];
-        for (int rr = D + 1; rr < Dp; rr++) col[rr] = 0;
+        if (lane == 0) {
+            col[c] += *lam;
+            gc_out[c] = col[D + 1]; // (this lane clears that entry below, in program order)
+        }
+        for (int rr = D + 1 + lane; rr < Dp; rr += 64) col[rr] = 0;
     } else {
-        for (int rr = c; rr < Dp; rr++) col[rr] = (rr == c) ? (T)1 : (T)0;
+        for (int rr = c + lane; rr < Dp; rr += 64) col[rr] = (rr == c) ? (T)1 : (T)0;
     }
 }
 

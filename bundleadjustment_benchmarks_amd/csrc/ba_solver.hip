@@ -403,7 +403,7 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_post_reduce()
     {
-        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p, d_dxc.p);
+        hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 3) / 4), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p, d_dxc.p);
     }
 
     int set_lambda(T lambda)
