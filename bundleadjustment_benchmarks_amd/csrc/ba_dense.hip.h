@@ -113,7 +113,7 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
     return u.f;
 }
 
-template <typename T, int NB, bool TOLDS>
+template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1]);
 template <typename T, int NB, bool TOLDS, bool STSC = false>
@@ -449,8 +449,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int r = idx % NB, c = idx / NB;
         // The factored diagonal block itself is only read again when it contains the rhs row (last block column,
         // single workgroup); other workgroups of a wider grid may still be loading the original block from S.
-        if (nblk_panel == 1 && c <= r && c < nb) S[(size_t)(p0 + c) * ld + p0 + r] = Ad[c][r];
-        Winv[c * NB + r] = (r <= c && c < nb) ? Wl[c][r] : (T)0; // here (c, r) = (row, column) of W
+        if (nblk_panel == 1 && c <= r && c < nb) __hip_atomic_store(&S[(size_t)(p0 + c) * ld + p0 + r], Ad[c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&Winv[c * NB + r], (r <= c && c < nb) ? Wl[c][r] : (T)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (c, r) = (row, column) of W
     }
     // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
     const int r0 = p0 + NB + 64 * blk + 16 * wv;
@@ -491,8 +491,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         for (int v = 0; v < 4; v++) {
             const int j = 16 * t + ba_crow<T>(lk, v); // column of the panel
             const T yv = acc[t][v];
-            Wp[(size_t)j * ld + r0 + li] = yv;
-            S[(size_t)(p0 + j) * ld + r0 + li] = yv * dinv[j];
+            // (write-through stores, like every bulk store of the factorisation: what a launch writes should leave the L2s
+            // while it runs, not in the release at its end -- the next launch reads it from other XCDs anyway)
+            __hip_atomic_store(&Wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     BA_STAMP_SEG(5);
     BA_STAMP_FLUSH
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
     const int tj = 1 + u;
     const int row0 = p0 + 64 * ti, col0 = p0 + 64 * tj;
     if (row0 >= nrows || col0 >= ncols) return;
-    ba_update_tile<T, NB, false>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
+    // (write-through stores: the 17 MB a launch writes leave the L2s while it runs, not in the release at its end)
+    ba_update_tile<T, NB, false, true>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
 }
 
 // Trailing update of one 64 x 64 tile with the 64-wide panel at block column p0: C_ij -= sum_k Y_ik L_jk.
@@ -615,11 +618,11 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
             }
 }
 
-template <typename T, int NB, bool TOLDS>
+template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
                                                const T *__restrict__ Wp, T (*Cl)[NB + 1])
 {
-    ba_update_quad<T, NB, TOLDS>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6); // wave w owns quadrant w
+    ba_update_quad<T, NB, TOLDS, STSC>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6); // wave w owns quadrant w
 }
 
 // Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
