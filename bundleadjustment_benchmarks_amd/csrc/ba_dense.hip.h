@@ -184,7 +184,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     for (int it = 0; it < NF; it++) {
         const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
         Ad[c][r] = fa[it];
-        Wl[c][r] = (T)0;
+        // (W's image needs no clearing: every entry that is read -- the lower tiles and the full diagonal tiles -- is written first)
     }
     __syncthreads();
     // Look-ahead: the trailing update of the PREVIOUS block column (p0 - 64) runs in this same launch on other workgroups,
