@@ -174,7 +174,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     if (INL && Wprev && wv < 2) {
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
-            t16a[kk] = -S[(size_t)(p0 - NB + 4 * kk + lk) * ld + p0 + li];
+            t16a[kk] = S[(size_t)(p0 - NB + 4 * kk + lk) * ld + p0 + li]; // (negated at use: a sign flip here makes the compiler
+                                                                          // wait for every older load before it issues the next)
             t16b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * wv + li];
         }
     }
@@ -197,7 +198,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int pp = p0 - NB;
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
-            a[kk] = -S[(size_t)(pp + 4 * kk + lk) * ld + p0 + 16 * tj + li]; // A[j][k] = L[j][k]
+            a[kk] = S[(size_t)(pp + 4 * kk + lk) * ld + p0 + 16 * tj + li]; // A[j][k] = L[j][k] (negated at use)
             b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * ti + li];   // B[k][i] = Y[i][k]
         }
     };
@@ -206,7 +207,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li];
 #pragma unroll
-        for (int kk = 0; kk < NB / 4; kk++) acc = ba_mfma(a[kk], b[kk], acc);
+        for (int kk = 0; kk < NB / 4; kk++) acc = ba_mfma(-a[kk], b[kk], acc);
 #pragma unroll
         for (int v = 0; v < 4; v++) Ad[16 * tj + ba_crow<T>(lk, v)][16 * ti + li] = acc[v];
     };
@@ -594,7 +595,7 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
         for (int q = 0; q < CH; q++) {
             const int kk = CH * half + q;
 #pragma unroll
-            for (int t = 0; t < 2; t++) a[q][t] = -S[(size_t)(p0 + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k]
+            for (int t = 0; t < 2; t++) a[q][t] = S[(size_t)(p0 + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k] (negated at use)
 #pragma unroll
             for (int u = 0; u < 2; u++) b[q][u] = Wp[(size_t)(4 * kk + lk) * ld + row0 + 16 * u + li];        // B[k][i] = Y[i][k]
         }
@@ -603,7 +604,7 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(a[q][t], b[q][u], acc[t][u]);
+                for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(-a[q][t], b[q][u], acc[t][u]);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++)
