@@ -265,14 +265,17 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     auto a3_tile = [&](int cs, int npv, int ti, int tj) {
         const int r0 = cs + 16 + 16 * ti, q0 = cs + 16 + 16 * tj;
         acc_t acc;
+        T la[4], yb[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = Ad[q0 + ba_crow<T>(lk, v)][r0 + li];
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            const T la = (4 * kk + lk < npv) ? -Ad[cs + 4 * kk + lk][q0 + li] : (T)0; // A[j][k] = L[j][k]
-            const T yb = Ys[4 * kk + lk][r0 + li];                                      // B[k][i] = Y[i][k]
-            acc = ba_mfma(la, yb, acc);
+            la[kk] = Ad[cs + 4 * kk + lk][q0 + li]; // A[j][k] = L[j][k]
+            yb[kk] = Ys[4 * kk + lk][r0 + li];      // B[k][i] = Y[i][k]
         }
+        __builtin_amdgcn_sched_barrier(0); // twelve LDS reads in flight, then the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = ba_mfma((4 * kk + lk < npv) ? -la[kk] : (T)0, yb[kk], acc);
 #pragma unroll
         for (int v = 0; v < 4; v++) Ad[q0 + ba_crow<T>(lk, v)][r0 + li] = acc[v];
     };
@@ -405,21 +408,29 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         {
             const int t = s + 1 + wv;
             if (t < 4) {
+                // (all LDS operands are requested before the first MFMA / the first store: left to itself the compiler reads
+                // each one right in front of its use and pays the LDS round trip eight times in a row)
                 acc_t acc;
-#pragma unroll
-                for (int v = 0; v < 4; v++) acc[v] = 0;
+                T wa[4], xb[4], dv[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
-                    const T wa = Wl[c0 + li][c0 + 4 * kk + lk];     // A[j][k] = W_ss[j][k]
-                    const T xb = Ad[c0 + 4 * kk + lk][16 * t + li]; // B[k][n] = X[n][k]
-                    acc = ba_mfma(wa, xb, acc);
+                    wa[kk] = Wl[c0 + li][c0 + 4 * kk + lk];     // A[j][k] = W_ss[j][k]
+                    xb[kk] = Ad[c0 + 4 * kk + lk][16 * t + li]; // B[k][n] = X[n][k]
                 }
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
+                    acc[v] = 0;
+                    dv[v] = dinv[c0 + ba_crow<T>(lk, v)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = ba_mfma(wa[kk], xb[kk], acc);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
                     const int j = ba_crow<T>(lk, v);
-                    const T yv = (j < np) ? acc[v] : (T)0; // columns past the last pivot do not take part
-                    Ys[j][16 * t + li] = yv;
-                    if (j < np) Ad[c0 + j][16 * t + li] = yv * dinv[c0 + j]; // L = Y D^-1
+                    const bool piv = j < np; // columns past the last pivot do not take part
+                    Ys[j][16 * t + li] = piv ? acc[v] : (T)0;
+                    if (piv) Ad[c0 + j][16 * t + li] = acc[v] * dv[v]; // L = Y D^-1
                 }
             }
         }
