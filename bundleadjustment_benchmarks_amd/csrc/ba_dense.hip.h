@@ -393,6 +393,14 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             // rows 1 and 2 of W (the last row with pivots follows the loop): under A1(3); a block with at most 48 pivots has
             // no fourth sub-panel, its row 1 is built under A1(2)
             if (s == 2 && h == 0 && nb <= 48) w_tile(1, 0, 0);
+            if (flags && own_rows && s == 3 && h == 1 && lane == 0) {
+                // the look-ahead update of this workgroup's rows by another workgroup of this launch (see k_ldlt_step) was
+                // finished long ago; a wave with time to spare makes sure here, so that the L2 round trip of the check is not
+                // in front of the row GEMM -- every wave reads the rows behind the barriers that follow
+                int spins = 0;
+                while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22))
+                    __builtin_amdgcn_s_sleep(4);
+            }
             if (s == 3) {
                 // ... and the sums of row 3, which do not need W_33 (being built by wave 1 right now): only the three
                 // 16 x 16 products W_3c = -W_33 T_c remain behind the loop
@@ -466,14 +474,6 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     }
     // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
     const int r0 = p0 + NB + 64 * blk + 16 * wv;
-    if (flags && own_rows) { // the look-ahead update of these rows by another workgroup of this launch (see k_ldlt_step)
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads(); // the rows are read with agent-scope loads below, by every wave behind this barrier
-    }
     if (r0 >= nrows || nb < NB) return;
     acc_t acc[4];
 #pragma unroll
