@@ -833,15 +833,20 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
     // operands of the group's own solve: thread (j, q) holds 16 rows of column j of W1, W0 and L10
     const int j = tid & 63, q = tid >> 6;
     const T *W0 = Winv + (size_t)fb * NB * NB, *W1 = W0 + (size_t)NB * NB;
+    // (unconditional loads from addresses that are valid either way: a load under `nbg == 2 ? ... : 0` is compiled as a branch
+    // with a wait behind every single load -- sixteen L2 round trips in a row at the head of the sweep)
+    const T *W1p = nbg == 2 ? W1 : W0;
     T w1[16], w0[16], l10[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const int k = 16 * q + t;
         w0[t] = W0[k * NB + j];
-        w1[t] = nbg == 2 ? W1[k * NB + j] : (T)0;
-        l10[t] = nbg == 2 ? S[(size_t)(c0 + j) * ld + c0 + NB + k] : (T)0; // L(c0 + 64 + k, c0 + j)
+        w1[t] = W1p[k * NB + j];
+        l10[t] = S[(size_t)(c0 + j) * ld + c0 + NB + k]; // L(c0 + 64 + k, c0 + j); unused (finite padding) when nbg == 1
     }
-    if (tid < 2 * NB) zs[tid] = (tid < ncg && c0 + tid < ncols) ? S[(size_t)(c0 + tid) * ld + zrow] : (T)0;
+    const int zc = c0 + (tid < ncg ? tid : 0);
+    T zv = S[(size_t)(zc < ncols ? zc : c0) * ld + zrow];
+    if (tid < 2 * NB) zs[tid] = (tid < ncg && c0 + tid < ncols) ? zv : (T)0;
     // elimination of the later groups: thread (j2, h) sums half h of the 128 rows of column j2
     const int j2 = tid & 127, h = tid >> 7;
     T lpre[NB];
