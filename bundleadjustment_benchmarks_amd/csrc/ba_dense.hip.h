@@ -300,26 +300,33 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             for (int c = 0; c < 4; c++) a[c] = Ad[c0 + 4 * q + c][c0 + i];
             ba_wave_lds_sync(); // the multipliers overwrite the tile: every lane has its entries first
             T *const junk = junkbuf + lane; // per-lane scratch slot
+            auto pivot = [&](int k) {
+                const int kq = k >> 2, kc = k & 3;
+                colx4[q][i] = a[kc];                          // column k is the kc-th register of the lanes with q == kq
+                const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
+                const T r = ba_rcp(dk);
+                ba_wave_lds_sync();
+                const T lraw = colx4[kq][i];
+                T y[4];
 #pragma unroll
-            for (int k = 0; k < 15; k++) { // pivot 15 has no rows below it in the tile: D(15) is final after pivot 14
-                if (k < np) { // uniform
-                    const int kq = k >> 2, kc = k & 3;
-                    colx4[q][i] = a[kc];                          // column k is the kc-th register of the lanes with q == kq
-                    const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
-                    const T r = ba_rcp(dk);
-                    ba_wave_lds_sync();
-                    const T lraw = colx4[kq][i];
-                    T y[4];
+                for (int c = 0; c < 4; c++) y[c] = colx4[kq][4 * q + c];
+                const T lm = (i > k) ? lraw : (T)0; // off the reciprocal's dependency chain
+                const T l = lm * r;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) y[c] = colx4[kq][4 * q + c];
-                    const T lm = (i > k) ? lraw : (T)0; // off the reciprocal's dependency chain
-                    const T l = lm * r;
+                for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
+                *((q == kq) ? &Ad[c0 + k][c0 + i] : junk) = l; // L(i, k); zero on and above the diagonal
+                __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
+            };
+            // pivot 15 has no rows below it in the tile: D(15) is final after pivot 14.  A full tile runs straight-line code;
+            // only the last, partial tile of the last block column tests the pivot count.
+            if (np == 16) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
-                    *((q == kq) ? &Ad[c0 + k][c0 + i] : junk) = l; // L(i, k); zero on and above the diagonal
-                    __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
-                }
+                for (int k = 0; k < 15; k++) pivot(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 15; k++)
+                    if (k < np) pivot(k); // uniform
             }
 #pragma unroll
             for (int c = 0; c < 4; c++)
@@ -332,31 +339,37 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             T w[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
+            auto wpivot = [&](int k) {
 #pragma unroll
-            for (int k = 0; k < 15; k++) { // pivot 15 has no rows below it: W_ss is complete one pivot before wave 0 is
-                if (k < np) { // uniform
+                for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
+                ba_wave_lds_sync();
+                T wk[4]; // row k of W is final since pivot k - 1: fetched before the wait for wave 0
 #pragma unroll
-                    for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
-                    ba_wave_lds_sync();
-                    T wk[4]; // row k of W is final since pivot k - 1: fetched before the wait for wave 0
+                for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
+                // column k of L is in Ad?  The multiplier is requested right behind the progress word (LDS executes a wave's
+                // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
+                // round trip together with the W row above, not three in a row.  (No s_sleep: its 64-cycle granularity is a
+                // whole LDS round trip.)
+                int pg;
+                T lr;
+                do {
+                    pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } while (pg < 16 * s + k + 1);
+                ba_wave_lds_sync();
+                const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
 #pragma unroll
-                    for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
-                    // column k of L is in Ad?  The multiplier is requested right behind the progress word (LDS executes a wave's
-                    // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
-                    // round trip together with the W row above, not three in a row.  (No s_sleep: its 64-cycle granularity is a
-                    // whole LDS round trip.)
-                    int pg;
-                    T lr;
-                    do {
-                        pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } while (pg < 16 * s + k + 1);
-                    ba_wave_lds_sync();
-                    const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
+                for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
+                ba_wave_lds_sync();
+            };
+            // pivot 15 has no rows below it: W_ss is complete one pivot before wave 0 is
+            if (np == 16) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
-                    ba_wave_lds_sync();
-                }
+                for (int k = 0; k < 15; k++) wpivot(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 15; k++)
+                    if (k < np) wpivot(k); // uniform
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
