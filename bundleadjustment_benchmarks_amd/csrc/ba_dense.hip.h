@@ -60,8 +60,9 @@ __device__ __forceinline__ float ba_rcp(float d)
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
+__device__ long long ba_stamp_own[4 * 4]; // own work of wave w in pivot-loop phase s: [4 * w + s]
 #define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); } /* own work before a barrier */
+#define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); if (blk == 0 && (threadIdx.x & 63) == 0) ba_stamp_own[4 * (threadIdx.x >> 6) + s] = (long long)(st_t1 - st_t0); } /* own work before a barrier */
 #define BA_STAMP_PRO0 unsigned long long st_p0; BA_STAMP_GET(st_p0);
 #define BA_STAMP_PRO unsigned long long st_p1; BA_STAMP_GET(st_p1); const long long st_pro = (long long)(st_p1 - st_p0);
 #define BA_STAMP_FLUSH if (blk == 0 && (threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; q_++) ba_stamp_acc[8 * (threadIdx.x >> 6) + q_] = st_acc[q_]; ba_stamp_acc[8 * (threadIdx.x >> 6) + 7] = st_pro; }

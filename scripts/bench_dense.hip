@@ -139,6 +139,8 @@ int main(int argc, char **argv)
         printf("fused step p=8: %.2f us (event to event); workgroup 0, wave 0: preamble %lld  A1 %lld  A2 %lld  A3 %lld  Wassembly %lld  publish+phaseB %lld  (sum %lld cycles)\n",
                fms * 1e3, hf[7], hf[0], hf[1], hf[3], hf[4], hf[5], hf[7] + hf[0] + hf[1] + hf[2] + hf[3] + hf[4] + hf[5]);
         printf("fused step p=8: own work inside the four A1 phases (before their barriers), waves 0..3: %lld %lld %lld %lld\n", hf[6], hf[14], hf[22], hf[30]);
+        long long ho[16]; CK(hipMemcpyFromSymbol(ho, HIP_SYMBOL(ba_stamp_own), sizeof(ho)));
+        for (int w = 0; w < 4; w++) printf("fused step p=8: wave %d own work per pivot-loop phase: %lld %lld %lld %lld\n", w, ho[4 * w], ho[4 * w + 1], ho[4 * w + 2], ho[4 * w + 3]);
     }
     for (int w = 0; w < 4; w++)
         printf("wave %d cycles: A1 %lld (own work %lld)  A2 %lld  scale %lld  A3 %lld  Wassembly %lld  publish+phaseB %lld\n", w, hs[8 * w], hs[8 * w + 6], hs[8 * w + 1],
