@@ -340,6 +340,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             T w[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
+            int pg = 0; // last value read from the progress word: a wave that is behind does not poll at all
             auto wpivot = [&](int k) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
@@ -351,12 +352,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
                 // round trip together with the W row above, not three in a row.  (No s_sleep: its 64-cycle granularity is a
                 // whole LDS round trip.)
-                int pg;
-                T lr;
-                do {
+                T lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (pg < 16 * s + k + 1) {
                     pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } while (pg < 16 * s + k + 1);
+                }
                 ba_wave_lds_sync();
                 const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
 #pragma unroll
