@@ -683,9 +683,15 @@ template <typename T> struct Solver final : SolverBase {
             // after an accepted step of a single-shard run the linearisation is already in the stream (try_step_impl, speculate);
             // its energy (== the test energy of that step, evaluated by the same code at the same point) is read back together
             // with the next trial
-            const bool lin_async = iter > 1 && world == 1 && use_graph && !keep;
-            if (lin_async) {
+            const bool lin_spec = iter > 1 && world == 1 && use_graph && !keep;
+            // sharded run: no speculation (the trial is not replayed), but the linearisation and the all-reduce of its energy
+            // are only enqueued as well -- the energy comes back with the scalars of the next trial, one host
+            // synchronisation per LM iteration instead of two
+            const bool lin_async = lin_spec || (iter > 1 && world > 1 && !keep);
+            if (lin_spec) {
                 // (already enqueued behind the accepted trial, speculatively, for the buffer that is now the current one)
+            } else if (lin_async) {
+                if ((rc = linearize_enqueue(false)) || (rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) break;
             } else {
                 if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
                 energy = (T)e;
