@@ -88,6 +88,28 @@ __device__ __forceinline__ void ba_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Ordering for the compiler only.  The LDS executes the instructions of ONE wave in order, so a load behind a store of the
+// same wave sees it without any s_waitcnt in between (a wavefront fence would emit one and put the store's round trip in
+// front of the load's: ~45 cycles per pivot in the loops below).
+__device__ __forceinline__ void ba_wave_lds_order() { asm volatile("" ::: "memory"); }
+// Lane K of every row of 16 lanes broadcast to that row (DPP row_newbcast): no LDS round trip.
+template <int K> __device__ __forceinline__ double ba_rowbcast(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int K> __device__ __forceinline__ float ba_rowbcast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + K, 0xf, 0xf, true)); }
+template <typename T> __device__ __forceinline__ T ba_rowbcast_k(T v, int k) // k is a constant after unrolling
+{
+    switch (k) {
+    case 0: return ba_rowbcast<0>(v); case 1: return ba_rowbcast<1>(v); case 2: return ba_rowbcast<2>(v); case 3: return ba_rowbcast<3>(v);
+    case 4: return ba_rowbcast<4>(v); case 5: return ba_rowbcast<5>(v); case 6: return ba_rowbcast<6>(v); case 7: return ba_rowbcast<7>(v);
+    case 8: return ba_rowbcast<8>(v); case 9: return ba_rowbcast<9>(v); case 10: return ba_rowbcast<10>(v); case 11: return ba_rowbcast<11>(v);
+    case 12: return ba_rowbcast<12>(v); case 13: return ba_rowbcast<13>(v); case 14: return ba_rowbcast<14>(v); default: return ba_rowbcast<15>(v);
+    }
+}
+
 #ifndef BA_SENTINEL_DEFINED
 #define BA_SENTINEL_DEFINED
 // A bit pattern no arithmetic produces (hardware NaNs are canonical): marks "not written yet" in a hand-off buffer.
@@ -155,7 +177,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // workgroups of the fused launch inherit the footprint).
     __shared__ T Ys[16][NB + 1];
 #define BA_TS(sc, r, c) Wl[(r)][16 * ((sc) + 1) + (c)] /* scratch tile sc = the (never read) strictly upper tile (0, sc + 1) of W */
-    __shared__ T colx4[4][16], wtile[16][17], dinv[NB], junkbuf[64];
+    __shared__ T colx4[4][16], dinv[NB], junkbuf[64];
     __shared__ int prog[64]; // A1 hand-off: pivots of the diagonal block whose multipliers are in Ad (per lane)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
@@ -301,23 +323,36 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             for (int c = 0; c < 4; c++) a[c] = Ad[c0 + 4 * q + c][c0 + i];
             ba_wave_lds_sync(); // the multipliers overwrite the tile: every lane has its entries first
             T *const junk = junkbuf + lane; // per-lane scratch slot
+            T lprev = (T)0;
+            int kdone = -1; // last pivot whose multipliers are still in lprev
+            auto lstore = [&](int k) { // L(., k) to its final place (zero on and above the diagonal) + the progress word
+                *((q == (k >> 2)) ? &Ad[c0 + k][c0 + i] : junk) = lprev;
+                __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            // One pivot = one LDS trip (column k out, five loads back, nothing waits for the store), the reciprocal (pivot by
+            // v_readlane; hardware estimate + two Newton steps, kept in front of the wait for the loads: the wave issues in
+            // order) and five FMAs.  The multipliers of pivot k - 1 are stored BEHIND the loads of pivot k, so that they
+            // queue in the LDS while the wave computes and not in front of the exchange (148 against 192 cycles per pivot alone).
             auto pivot = [&](int k) {
                 const int kq = k >> 2, kc = k & 3;
-                colx4[q][i] = a[kc];                          // column k is the kc-th register of the lanes with q == kq
-                const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
-                const T r = ba_rcp(dk);
-                ba_wave_lds_sync();
+                colx4[q][i] = a[kc]; // column k is the kc-th register of the lanes with q == kq
+                ba_wave_lds_order();
                 const T lraw = colx4[kq][i];
                 T y[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) y[c] = colx4[kq][4 * q + c];
-                const T lm = (i > k) ? lraw : (T)0; // off the reciprocal's dependency chain
+                ba_wave_lds_order();
+                if (k > 0) lstore(k - 1);
+                ba_wave_lds_order();
+                const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
+                const T r = ba_rcp(dk);
+                __builtin_amdgcn_sched_barrier(0);
+                const T lm = (i > k) ? lraw : (T)0;
                 const T l = lm * r;
 #pragma unroll
                 for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
-                *((q == kq) ? &Ad[c0 + k][c0 + i] : junk) = l; // L(i, k); zero on and above the diagonal
-                __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ba_wave_lds_sync(); // the next pivot's stores must stay behind this pivot's loads
+                lprev = l;
+                kdone = k;
             };
             // pivot 15 has no rows below it in the tile: D(15) is final after pivot 14.  A full tile runs straight-line code;
             // only the last, partial tile of the last block column tests the pivot count.
@@ -329,6 +364,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 for (int k = 0; k < 15; k++)
                     if (k < np) pivot(k); // uniform
             }
+            if (kdone >= 0) lstore(kdone);
 #pragma unroll
             for (int c = 0; c < 4; c++)
                 if (4 * q + c == i && i < np) {
@@ -342,26 +378,20 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
             int pg = 0; // last value read from the progress word: a wave that is behind does not poll at all
             auto wpivot = [&](int k) {
+                T wk[4]; // row k of W (final since pivot k - 1) sits in lane k of every row of 16 lanes: DPP broadcast, no LDS
 #pragma unroll
-                for (int c = 0; c < 4; c++) wtile[i][4 * q + c] = w[c]; // row k of W is wtile[k][.]
-                ba_wave_lds_sync();
-                T wk[4]; // row k of W is final since pivot k - 1: fetched before the wait for wave 0
-#pragma unroll
-                for (int c = 0; c < 4; c++) wk[c] = wtile[k][4 * q + c];
+                for (int c = 0; c < 4; c++) wk[c] = ba_rowbcast_k(w[c], k);
                 // column k of L is in Ad?  The multiplier is requested right behind the progress word (LDS executes a wave's
                 // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
-                // round trip together with the W row above, not three in a row.  (No s_sleep: its 64-cycle granularity is a
-                // whole LDS round trip.)
+                // round trip.  (No s_sleep: its 64-cycle granularity is a whole LDS round trip.)
                 T lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 while (pg < 16 * s + k + 1) {
                     pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                ba_wave_lds_sync();
                 const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
 #pragma unroll
                 for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
-                ba_wave_lds_sync();
             };
             // pivot 15 has no rows below it: W_ss is complete one pivot before wave 0 is
             if (np == 16) {
