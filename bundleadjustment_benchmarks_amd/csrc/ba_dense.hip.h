@@ -61,6 +61,9 @@ __device__ __forceinline__ float ba_rcp(float d)
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
 __device__ long long ba_stamp_own[4 * 4]; // own work of wave w in pivot-loop phase s: [4 * w + s]
+__device__ int ba_stamp_spin[16];         // inverse wave, phase 2: failed polls per pivot
+__device__ long long ba_stamp_piv[4 * 4]; // phase s: factor wave has its tile [4 * s], has done its pivots [+ 1]; inverse wave done [+ 2]
+#define BA_STAMP_PIV(j) { unsigned long long t_; BA_STAMP_GET(t_); if (blk == 0 && lane == 0) ba_stamp_piv[4 * s + j] = (long long)(t_ - st_t0); }
 #define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); if (blk == 0 && (threadIdx.x & 63) == 0) ba_stamp_own[4 * (threadIdx.x >> 6) + s] = (long long)(st_t1 - st_t0); } /* own work before a barrier */
 #define BA_STAMP_PRO0 unsigned long long st_p0; BA_STAMP_GET(st_p0);
@@ -76,6 +79,7 @@ __device__ long long ba_stamp_own[4 * 4]; // own work of wave w in pivot-loop ph
 #define BA_STAMP_FLUSH
 #define BA_STAMP_GET(v)
 #define BA_STAMP_SEG(i)
+#define BA_STAMP_PIV(j)
 #endif
 
 // LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the
@@ -93,13 +97,8 @@ __device__ __forceinline__ void ba_wave_lds_sync()
 // front of the load's: ~45 cycles per pivot in the loops below).
 __device__ __forceinline__ void ba_wave_lds_order() { asm volatile("" ::: "memory"); }
 // Lane K of every row of 16 lanes broadcast to that row (DPP row_newbcast): no LDS round trip.
-template <int K> __device__ __forceinline__ double ba_rowbcast(double v)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int K> __device__ __forceinline__ float ba_rowbcast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + K, 0xf, 0xf, true)); }
+template <int K> __device__ __forceinline__ double ba_rowbcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, true); } // ONE v_mov_b64_dpp
+template <int K> __device__ __forceinline__ float ba_rowbcast(float v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, true); }
 template <typename T> __device__ __forceinline__ T ba_rowbcast_k(T v, int k) // k is a constant after unrolling
 {
     switch (k) {
@@ -242,7 +241,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     if (Wprev && wv < 2) {
         if (!INL) tile16_load(wv, 0, t16a, t16b);
         tile16_apply(wv, 0, t16a, t16b);
-        ba_wave_lds_sync(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
+        ba_wave_lds_order(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
     BA_STAMP_PRO
     const int rown = p0 + NB + 64 * blk;
@@ -266,7 +265,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             }
 #pragma unroll
         for (int v = 0; v < 4; v++) BA_TS(scratch, ba_crow<T>(lk, v), li) = acc[v];
-        ba_wave_lds_sync();
+        ba_wave_lds_order();
     };
     auto w_fin = [&](int t, int sc, int scratch) {
         acc_t acc2;
@@ -280,7 +279,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         }
 #pragma unroll
         for (int v = 0; v < 4; v++) Wl[16 * t + ba_crow<T>(lk, v)][16 * sc + li] = acc2[v];
-        ba_wave_lds_sync();
+        ba_wave_lds_order();
     };
     auto w_tile = [&](int t, int sc, int scratch) { w_sum(t, sc, scratch); w_fin(t, sc, scratch); };
     // rank-16 update by the sub-panel at column cs (npv pivots) of tile (ti, tj) counted from the tile behind it:
@@ -321,7 +320,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             T a[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) a[c] = Ad[c0 + 4 * q + c][c0 + i];
-            ba_wave_lds_sync(); // the multipliers overwrite the tile: every lane has its entries first
+            ba_wave_lds_order(); // the multipliers overwrite the tile: every lane has its entries first
+            BA_STAMP_PIV(0)
             T *const junk = junkbuf + lane; // per-lane scratch slot
             T lprev = (T)0;
             int kdone = -1; // last pivot whose multipliers are still in lprev
@@ -364,13 +364,17 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 for (int k = 0; k < 15; k++)
                     if (k < np) pivot(k); // uniform
             }
+            BA_STAMP_PIV(1)
             if (kdone >= 0) lstore(kdone);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (4 * q + c == i && i < np) {
-                    Ad[c0 + i][c0 + i] = a[c]; // D(i)
-                    dinv[c0 + i] = ba_rcp(a[c]);
+            { // D(i) sits in register i % 4 of lane (i, i / 4): selected, so that there is ONE reciprocal and not one per register
+              // in four divergent branches (-200 cycles per sub-panel)
+                const int ic = i & 3;
+                const T dsel = (ic == 0) ? a[0] : (ic == 1) ? a[1] : (ic == 2) ? a[2] : a[3];
+                if (q == (i >> 2) && i < np) {
+                    Ad[c0 + i][c0 + i] = dsel; // D(i)
+                    dinv[c0 + i] = ba_rcp(dsel);
                 }
+            }
         } else if (wv == 1) {
             const int i = li, q = lk;
             T w[4];
@@ -385,10 +389,19 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
                 // round trip.  (No s_sleep: its 64-cycle granularity is a whole LDS round trip.)
                 T lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef BA_STAMP
+                int spins_ = 0;
+#endif
                 while (pg < 16 * s + k + 1) {
                     pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef BA_STAMP
+                    spins_++;
+#endif
                 }
+#ifdef BA_STAMP
+                if (blk == 0 && lane == 0 && s == 2) ba_stamp_spin[k] = spins_;
+#endif
                 const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
 #pragma unroll
                 for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
@@ -402,6 +415,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 for (int k = 0; k < 15; k++)
                     if (k < np) wpivot(k); // uniform
             }
+            BA_STAMP_PIV(2)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int j = 4 * q + c;
@@ -494,7 +508,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         // (they are read by A2 / A1 of later sub-panels, i.e. behind the barrier that ends it).
         if (wv == 0) {
             a3_tile(c0, np, 0, 0);
-            ba_wave_lds_sync();
+            ba_wave_lds_order();
         }
         BA_STAMP_SEG(3);
     }

@@ -115,10 +115,15 @@ int main(int argc, char **argv)
     printf("relative residual |Sx-b|/|b| = %.3e\n", std::sqrt(rn / bn));
 #ifdef BA_STAMP
     CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
-    hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(2), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
+    for (int r = 0; r < (argc > 2 ? atoi(argv[2]) : 1); r++) // (argv[2] > 1: is the instruction cache still warm in the next launch?)
+        hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(1), dim3(256), 0, st, nrows, ncols, ld, 0, S, Wp, Winv);
     CK(hipStreamSynchronize(st));
     long long hs[64]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_stamp_acc), sizeof(hs)));
     for (int w = 0; w < 4; w++) printf("classic panel wave %d: preamble %lld\n", w, hs[8 * w + 7]);
+    { long long ho[16]; CK(hipMemcpyFromSymbol(ho, HIP_SYMBOL(ba_stamp_own), sizeof(ho)));
+      for (int w = 0; w < 2; w++) printf("classic panel (no look-ahead work): wave %d own work per pivot-loop phase: %lld %lld %lld %lld\n", w, ho[4 * w], ho[4 * w + 1], ho[4 * w + 2], ho[4 * w + 3]);
+      long long hp[16]; CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(ba_stamp_piv), sizeof(hp)));
+      for (int ph = 0; ph < 4; ph++) printf("classic panel: factor wave, phase %d: tile in registers at %lld, fifteen pivots done at %lld\n", ph, hp[4 * ph], hp[4 * ph + 1]); }
     { // stamps of a fused step in the middle of the factorisation (block column 8) and its duration
         CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
         hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
@@ -140,6 +145,9 @@ int main(int argc, char **argv)
                fms * 1e3, hf[7], hf[0], hf[1], hf[3], hf[4], hf[5], hf[7] + hf[0] + hf[1] + hf[2] + hf[3] + hf[4] + hf[5]);
         printf("fused step p=8: own work inside the four A1 phases (before their barriers), waves 0..3: %lld %lld %lld %lld\n", hf[6], hf[14], hf[22], hf[30]);
         long long ho[16]; CK(hipMemcpyFromSymbol(ho, HIP_SYMBOL(ba_stamp_own), sizeof(ho)));
+        { long long hp[16]; CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(ba_stamp_piv), sizeof(hp)));
+          for (int ph = 0; ph < 4; ph++) printf("fused step p=8: factor wave, phase %d: tile in registers at %lld, fifteen pivots done at %lld; inverse wave done at %lld\n", ph, hp[4 * ph], hp[4 * ph + 1], hp[4 * ph + 2]); }
+        { int sp[16]; CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(ba_stamp_spin), sizeof(sp))); printf("fused step p=8: inverse wave, phase 2, failed polls per pivot:"); for (int k = 0; k < 15; k++) printf(" %d", sp[k]); printf("\n"); }
         for (int w = 0; w < 4; w++) printf("fused step p=8: wave %d own work per pivot-loop phase: %lld %lld %lld %lld\n", w, ho[4 * w], ho[4 * w + 1], ho[4 * w + 2], ho[4 * w + 3]);
     }
     for (int w = 0; w < 4; w++)
