@@ -57,6 +57,12 @@ __device__ __forceinline__ float ba_rcp(float d)
 
 #define BA_NB 64
 
+// compile-time list of (up to four) tile indices
+template <int N, int T0, int T1, int T2, int T3> struct ba_tiles {
+    static constexpr int n = N;
+    static __device__ constexpr int t(int u) { return u == 0 ? T0 : u == 1 ? T1 : u == 2 ? T2 : T3; }
+};
+
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
@@ -244,7 +250,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         ba_wave_lds_order(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
     BA_STAMP_PRO
-    const int rown = p0 + NB + 64 * blk;
+    // INL (the variant whose rows are updated by other workgroups): TWO panel workgroups per 64-row block, 32 rows each -- the
+    // row GEMM behind the factorisation is MFMA-bound (40 x 64 cycles per wave for 64 rows) and the CUs are there.
+    constexpr bool HALVES = INL;
+    const int rblk = HALVES ? (blk >> 1) : blk;
+    const int rown = p0 + NB + 64 * rblk;
     const bool own_rows = Wprev != nullptr && rown < nrows;
     BA_STAMP_DECL
     BA_STAMP_GET(st_t0);
@@ -530,42 +540,51 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         if (nblk_panel == 1 && c <= r && c < nb) __hip_atomic_store(&S[(size_t)(p0 + c) * ld + p0 + r], Ad[c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&Winv[c * NB + r], (r <= c && c < nb) ? Wl[c][r] : (T)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (c, r) = (row, column) of W
     }
-    // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores; wave w owns 16 rows
-    const int r0 = p0 + NB + 64 * blk + 16 * wv;
+    // ---- rows below the diagonal block: Y^T = W X^T on the matrix cores.  Wave w owns 16 rows and all four 16-wide column
+    // tiles of the panel (40 MFMAs: W is lower triangular); with two workgroups per row block 16 rows and two column tiles
+    // (0 and 3 or 1 and 2: 20 MFMAs either way).
+    const int r0 = HALVES ? p0 + NB + 64 * rblk + 32 * (blk & 1) + 16 * (wv & 1) : p0 + NB + 64 * blk + 16 * wv;
     if (r0 >= nrows || nb < NB) return;
-    acc_t acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) acc[t][v] = 0;
     T xall[NB / 4]; // all sixteen loads in flight before the first MFMA (one L2 round trip instead of four)
 #pragma unroll
     for (int kk = 0; kk < NB / 4; kk++) // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold
                                         // the pre-update lines
         xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_sched_barrier(0);
+    auto rowgemm = [&](auto tiles) { // tiles: the column tiles of this wave (compile-time list)
+        constexpr int NT = decltype(tiles)::n;
+        acc_t acc[NT];
 #pragma unroll
-    for (int kk = 0; kk < NB / 4; kk++) {
-        const T xb = xall[kk];
+        for (int u = 0; u < NT; u++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
-                const T wa = Wl[16 * t + li][4 * kk + lk]; // A[j][k]
-                acc[t] = ba_mfma(wa, xb, acc[t]);
+            for (int v = 0; v < 4; v++) acc[u][v] = 0;
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) {
+            const T xb = xall[kk];
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const int t = decltype(tiles)::t(u);
+                if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
+                    const T wa = Wl[16 * t + li][4 * kk + lk]; // A[j][k]
+                    acc[u] = ba_mfma(wa, xb, acc[u]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+        for (int u = 0; u < NT; u++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int j = 16 * t + ba_crow<T>(lk, v); // column of the panel
-            const T yv = acc[t][v];
-            // (write-through stores, like every bulk store of the factorisation: what a launch writes should leave the L2s
-            // while it runs, not in the release at its end -- the next launch reads it from other XCDs anyway)
-            __hip_atomic_store(&Wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+            for (int v = 0; v < 4; v++) {
+                const int j = 16 * decltype(tiles)::t(u) + ba_crow<T>(lk, v); // column of the panel
+                const T yv = acc[u][v];
+                // (write-through stores, like every bulk store of the factorisation: what a launch writes should leave the L2s
+                // while it runs, not in the release at its end -- the next launch reads it from other XCDs anyway)
+                __hip_atomic_store(&Wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    };
+    if (!HALVES) rowgemm(ba_tiles<4, 0, 1, 2, 3>());
+    else if (wv < 2) rowgemm(ba_tiles<2, 0, 3, 0, 0>());
+    else rowgemm(ba_tiles<2, 1, 2, 0, 0>());
     BA_STAMP_SEG(5);
     BA_STAMP_FLUSH
 }

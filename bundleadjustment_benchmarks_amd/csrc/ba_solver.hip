@@ -387,7 +387,8 @@ template <typename T> struct Solver final : SolverBase {
                 // workgroup).  Beyond, the update dominates: out-of-line variant, 116 VGPRs + < 80 KiB LDS = two per CU.
                 if (nblk < 48) {
                     const int nq = below > 0 ? npanel : 0; // workgroups that update the panel workgroups' rows (see k_ldlt_step)
-                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + npanel + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, npanel,
+                    const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
+                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2,
                                        d_S.p, wcur, wprev, d_Winv.p + (size_t)p * NB * NB, nq, d_flags.p);
                 }
                 else

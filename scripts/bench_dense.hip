@@ -60,7 +60,7 @@ int main(int argc, char **argv)
                 const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                if (nblk < 48) { const int nq = below > 0 ? g : 0; hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(nq + g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB, nq, flags); } else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+                if (nblk < 48) { const int nq = below > 0 ? g : 0, g2 = below > 0 ? 2 * g : 1; hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(nq + g2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g2, S, wcur, wprev, Winv + (size_t)p * NB * NB, nq, flags); } else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
             }
         }
         CK(hipEventRecord(e1, st));
@@ -135,7 +135,7 @@ int main(int argc, char **argv)
             int nupd = 0;
             for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
             if (p == 8) CK(hipEventRecord(f0, st));
-            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(2 * g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB, g, flags);
+            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(3 * g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, 2 * g, S, wcur, wprev, Winv + (size_t)p * NB * NB, g, flags);
             if (p == 8) CK(hipEventRecord(f1, st));
         }
         CK(hipStreamSynchronize(st));
