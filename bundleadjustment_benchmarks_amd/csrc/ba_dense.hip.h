@@ -67,8 +67,7 @@ template <int N, int T0, int T1, int T2, int T3> struct ba_tiles {
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
 __device__ long long ba_stamp_own[4 * 4]; // own work of wave w in pivot-loop phase s: [4 * w + s]
-__device__ int ba_stamp_spin[16];         // inverse wave, phase 2: failed polls per pivot
-__device__ long long ba_stamp_piv[4 * 4]; // phase s: factor wave has its tile [4 * s], has done its pivots [+ 1]; inverse wave done [+ 2]
+__device__ long long ba_stamp_piv[4 * 4]; // phase s: factor wave has its tile [4 * s], has done its pivots [+ 1]
 #define BA_STAMP_PIV(j) { unsigned long long t_; BA_STAMP_GET(t_); if (blk == 0 && lane == 0) ba_stamp_piv[4 * s + j] = (long long)(t_ - st_t0); }
 #define BA_STAMP_DECL unsigned long long st_t0 = 0, st_t1 = 0; long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BA_STAMP_OWN(i) { BA_STAMP_GET(st_t1); st_acc[i] += (long long)(st_t1 - st_t0); if (blk == 0 && (threadIdx.x & 63) == 0) ba_stamp_own[4 * (threadIdx.x >> 6) + s] = (long long)(st_t1 - st_t0); } /* own work before a barrier */
@@ -159,9 +158,10 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 // Every workgroup factors the 64x64 diagonal block itself (it is the critical path; a broadcast would cost a kernel
 // boundary).  The pivot recurrence d_k -> 1/d_k -> l_ik -> d_k+1 is pure latency on this machine (a dependent f64 FMA
 // is ~32 cycles, one wave issues an f64 op every ~9 cycles), so the block is processed in four 16-wide sub-panels:
-//   A1  wave 0 factors the 16x16 diagonal tile in registers (4 entries per lane), wave 1 inverts it with the same row
-//       operations one pivot behind (LDS progress word, no barriers); the pivot is broadcast with v_readlane so the
-//       reciprocal chain (estimate + Newton) starts before the LDS exchange of the column has finished;
+//   A1  wave 0 factors the 16x16 diagonal tile in registers (4 entries per lane) and carries its inverse along (the same
+//       row operations on I, one pivot late, in the shadow of the next column exchange); the pivot is broadcast with
+//       v_readlane so the reciprocal chain (estimate + Newton) starts before the LDS exchange of the column has finished;
+//       the other three waves do the look-ahead update of the block, the deferred rank-16 updates and the W products;
 //   A2  the tiles below (inside the 64x64 block) get Y = X W_ss^T on the matrix cores;
 //   A3  the remaining tiles of the block get the rank-16 update on the matrix cores.
 // W = L11^-1 (64x64) is then assembled from the four 16x16 inverses with MFMA products, and the rows below the diagonal
@@ -183,7 +183,6 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     __shared__ T Ys[16][NB + 1];
 #define BA_TS(sc, r, c) Wl[(r)][16 * ((sc) + 1) + (c)] /* scratch tile sc = the (never read) strictly upper tile (0, sc + 1) of W */
     __shared__ T colx4[4][16], dinv[NB], junkbuf[64];
-    __shared__ int prog[64]; // A1 hand-off: pivots of the diagonal block whose multipliers are in Ad (per lane)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int nb = min(NB, ncols - p0);
     BA_STAMP_PRO0
@@ -207,7 +206,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             t16b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * wv + li];
         }
     }
-    if (tid < NB) { dinv[tid] = (T)0; prog[tid] = 0; }
+    if (tid < NB) dinv[tid] = (T)0;
     typedef typename ba_acc<T>::type acc_t;
 #pragma unroll
     for (int it = 0; it < NF; it++) {
@@ -317,12 +316,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         const int np = min(16, nb - c0); // pivots in this sub-panel
         if (np <= 0) break;              // uniform
         // ---- A1: 16x16 diagonal tile; lane (i, q) owns row i, columns 4q .. 4q+3.
-        // A single wave issues one f64-class VALU instruction every ~8 cycles and the pivot loop is bound by that issue
-        // rate, so the work of a pivot is split over two waves (two SIMDs):
-        //   wave 0 factors the tile (column k -> LDS, pivot by v_readlane, reciprocal, multipliers, rank-1 update) and
-        //          never waits for anybody; the multipliers go straight to their final place in Ad and a per-lane progress
-        //          word tells wave 1 that column k is there (LDS executes a wave's instructions in order);
-        //   wave 1 applies the same row operations to I (W_ss = L_ss^-1), one pivot behind.
+        // Wave 0 factors the tile (column k -> LDS, pivot by v_readlane, reciprocal, multipliers, rank-1 update) and applies
+        // the same row operations to I one pivot late (W_ss = L_ss^-1: the multiplier is the lane's own register, row k of W
+        // a DPP row broadcast, so the inverse costs no LDS traffic and hides in the wait for the next column exchange; a
+        // second wave fed through LDS finished ~800 cycles behind the factor wave in every sub-panel).
         // D(k) stays in its register until the end (row k is never touched after pivot k); 1/D(k) is recomputed there by
         // the same instruction sequence, so the loop stores nothing but the multipliers.
         if (wv == 0) {
@@ -334,10 +331,19 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             BA_STAMP_PIV(0)
             T *const junk = junkbuf + lane; // per-lane scratch slot
             T lprev = (T)0;
-            int kdone = -1; // last pivot whose multipliers are still in lprev
-            auto lstore = [&](int k) { // L(., k) to its final place (zero on and above the diagonal) + the progress word
+            T w[4];         // W_ss = L_ss^-1 in the same layout: the row operations of the factorisation applied to I, one pivot late
+#pragma unroll
+            for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
+            // what is left of pivot k once its multipliers exist: L(., k) to its final place (zero on and above the diagonal),
+            // and the same row operation on W -- the multiplier is the lane's own register and row k of W sits in lane k of every
+            // row of 16 lanes (DPP broadcast), so this is eight VALU instructions that fill the wait for the NEXT exchange
+            auto lstore = [&](int k) {
                 *((q == (k >> 2)) ? &Ad[c0 + k][c0 + i] : junk) = lprev;
-                __hip_atomic_store(&prog[lane], 16 * s + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                T wk[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) wk[c] = ba_rowbcast_k(w[c], k);
+#pragma unroll
+                for (int c = 0; c < 4; c++) w[c] -= lprev * wk[c];
             };
             // One pivot = one LDS trip (column k out, five loads back, nothing waits for the store), the reciprocal (pivot by
             // v_readlane; hardware estimate + two Newton steps, kept in front of the wait for the loads: the wave issues in
@@ -362,20 +368,28 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
                 for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
                 lprev = l;
-                kdone = k;
             };
             // pivot 15 has no rows below it in the tile: D(15) is final after pivot 14.  A full tile runs straight-line code;
             // only the last, partial tile of the last block column tests the pivot count.
+            // (the last pivot's multipliers are flushed where its index is a compile-time constant: the DPP control is an immediate)
             if (np == 16) {
 #pragma unroll
                 for (int k = 0; k < 15; k++) pivot(k);
+                BA_STAMP_PIV(1)
+                lstore(14);
             } else {
 #pragma unroll
                 for (int k = 0; k < 15; k++)
-                    if (k < np) pivot(k); // uniform
+                    if (k < np) { // uniform
+                        pivot(k);
+                        if (k + 1 == np || k == 14) lstore(k);
+                    }
             }
-            BA_STAMP_PIV(1)
-            if (kdone >= 0) lstore(kdone);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = 4 * q + c;
+                Wl[c0 + i][c0 + j] = (j <= i) ? w[c] : (T)0;
+            }
             { // D(i) sits in register i % 4 of lane (i, i / 4): selected, so that there is ONE reciprocal and not one per register
               // in four divergent branches (-200 cycles per sub-panel)
                 const int ic = i & 3;
@@ -386,59 +400,20 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 }
             }
         } else if (wv == 1) {
-            const int i = li, q = lk;
-            T w[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) w[c] = (4 * q + c == i) ? (T)1 : (T)0;
-            int pg = 0; // last value read from the progress word: a wave that is behind does not poll at all
-            auto wpivot = [&](int k) {
-                T wk[4]; // row k of W (final since pivot k - 1) sits in lane k of every row of 16 lanes: DPP broadcast, no LDS
-#pragma unroll
-                for (int c = 0; c < 4; c++) wk[c] = ba_rowbcast_k(w[c], k);
-                // column k of L is in Ad?  The multiplier is requested right behind the progress word (LDS executes a wave's
-                // instructions in order: it is valid whenever the word already says so), so a successful poll costs one LDS
-                // round trip.  (No s_sleep: its 64-cycle granularity is a whole LDS round trip.)
-                T lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef BA_STAMP
-                int spins_ = 0;
-#endif
-                while (pg < 16 * s + k + 1) {
-                    pg = __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    lr = __hip_atomic_load(&Ad[c0 + k][c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef BA_STAMP
-                    spins_++;
-#endif
-                }
-#ifdef BA_STAMP
-                if (blk == 0 && lane == 0 && s == 2) ba_stamp_spin[k] = spins_;
-#endif
-                const T l = (i > k) ? lr : (T)0; // wave 0 may already have put D(k) on the diagonal
-#pragma unroll
-                for (int c = 0; c < 4; c++) w[c] -= l * wk[c];
-            };
-            // pivot 15 has no rows below it: W_ss is complete one pivot before wave 0 is
-            if (np == 16) {
-#pragma unroll
-                for (int k = 0; k < 15; k++) wpivot(k);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 15; k++)
-                    if (k < np) wpivot(k); // uniform
-            }
-            BA_STAMP_PIV(2)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int j = 4 * q + c;
-                Wl[c0 + i][c0 + j] = (j <= i) ? w[c] : (T)0;
+            // (The inverse rides on wave 0.)  Under the second pivot loop this wave takes the deferred rank-16 updates of the
+            // tiles that get no look-ahead update in that phase -- (2,1), (3,2), (3,3) -- which leaves waves 2 and 3 one
+            // rank-16 update + one look-ahead tile each.
+            if (s == 1) {
+                a3_tile(0, 16, 1, 0);
+                a3_tile(0, 16, 2, 1);
+                a3_tile(0, 16, 2, 2);
             }
         } else {
             const int h = wv - 2;
-            if (s >= 1) { // the rank-16 updates by sub-panel s - 1 that wave 0 left behind: diagonal tiles to wave 3, the others to
-                          // wave 2 (the same wave that applies a tile's look-ahead update below: no two waves on one tile)
-                const int ntr = 4 - s;
-                for (int ti = 0; ti < ntr; ti++)
-                    for (int tj = 0; tj <= ti; tj++)
-                        if (ti + tj > 0 && ((ti == tj) ? 1 : 0) == h) a3_tile(16 * (s - 1), 16, ti, tj);
+            if (s >= 1) { // the rank-16 updates by sub-panel s - 1 that wave 0 left behind, each on the wave that applies the same
+                          // tile's look-ahead update below (no two waves on one tile)
+                if (s == 1) a3_tile(0, 16, h == 0 ? 2 : 1, h == 0 ? 0 : 1); // (3,1) | (2,2); wave 1 has the other three
+                if (s == 2) a3_tile(16, 16, 1, h);                          // (3,2) | (3,3)
             }
             if (flags) {
                 // The rest of the diagonal block's look-ahead update, at most two tiles per wave and sub-panel (a tile costs
@@ -545,46 +520,78 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // (0 and 3 or 1 and 2: 20 MFMAs either way).
     const int r0 = HALVES ? p0 + NB + 64 * rblk + 32 * (blk & 1) + 16 * (wv & 1) : p0 + NB + 64 * blk + 16 * wv;
     if (r0 >= nrows || nb < NB) return;
-    T xall[NB / 4]; // all sixteen loads in flight before the first MFMA (one L2 round trip instead of four)
+    if constexpr (!HALVES) {
+        acc_t acc[4];
 #pragma unroll
-    for (int kk = 0; kk < NB / 4; kk++) // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold
-                                        // the pre-update lines
-        xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_sched_barrier(0);
-    auto rowgemm = [&](auto tiles) { // tiles: the column tiles of this wave (compile-time list)
-        constexpr int NT = decltype(tiles)::n;
-        acc_t acc[NT];
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int u = 0; u < NT; u++)
+            for (int v = 0; v < 4; v++) acc[t][v] = 0;
+        T xall[NB / 4]; // all sixteen loads in flight before the first MFMA (one L2 round trip instead of four)
 #pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] = 0;
+        for (int kk = 0; kk < NB / 4; kk++) // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold
+                                            // the pre-update lines
+            xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
             const T xb = xall[kk];
 #pragma unroll
-            for (int u = 0; u < NT; u++) {
-                const int t = decltype(tiles)::t(u);
+            for (int t = 0; t < 4; t++) {
                 if (kk <= 4 * t + 3) { // W is lower triangular: W[j][k] = 0 for k > j
                     const T wa = Wl[16 * t + li][4 * kk + lk]; // A[j][k]
-                    acc[u] = ba_mfma(wa, xb, acc[u]);
+                    acc[t] = ba_mfma(wa, xb, acc[t]);
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < NT; u++)
+        for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const int j = 16 * decltype(tiles)::t(u) + ba_crow<T>(lk, v); // column of the panel
-                const T yv = acc[u][v];
+                const int j = 16 * t + ba_crow<T>(lk, v); // column of the panel
+                const T yv = acc[t][v];
                 // (write-through stores, like every bulk store of the factorisation: what a launch writes should leave the L2s
                 // while it runs, not in the release at its end -- the next launch reads it from other XCDs anyway)
                 __hip_atomic_store(&Wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-    };
-    if (!HALVES) rowgemm(ba_tiles<4, 0, 1, 2, 3>());
-    else if (wv < 2) rowgemm(ba_tiles<2, 0, 3, 0, 0>());
-    else rowgemm(ba_tiles<2, 1, 2, 0, 0>());
+    } else {
+        T xall[NB / 4];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++)
+            xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        auto rowgemm = [&](auto tiles) { // tiles: the two column tiles of this wave (compile-time list)
+            constexpr int NT = decltype(tiles)::n;
+            acc_t acc[NT];
+#pragma unroll
+            for (int u = 0; u < NT; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[u][v] = 0;
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; kk++) {
+                const T xb = xall[kk];
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const int t = decltype(tiles)::t(u);
+                    if (kk <= 4 * t + 3) {
+                        const T wa = Wl[16 * t + li][4 * kk + lk];
+                        acc[u] = ba_mfma(wa, xb, acc[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NT; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int j = 16 * decltype(tiles)::t(u) + ba_crow<T>(lk, v);
+                    const T yv = acc[u][v];
+                    __hip_atomic_store(&Wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        };
+        if (wv < 2) rowgemm(ba_tiles<2, 0, 3, 0, 0>());
+        else rowgemm(ba_tiles<2, 1, 2, 0, 0>());
+    }
     BA_STAMP_SEG(5);
     BA_STAMP_FLUSH
 }

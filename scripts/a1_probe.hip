@@ -50,13 +50,40 @@ template <int V> __global__ __launch_bounds__(256) void probe(long long *out, do
     T *const junk = junkbuf + lane;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int rep = 0; rep < reps; rep++) {
-        T a[4], lprev = 0;
+        T a[4], lprev = 0, wi[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) a[c] = tile[(4 * q + c) * 16 + i] + (T)rep * 1e-9;
+        for (int c = 0; c < 4; c++) { a[c] = tile[(4 * q + c) * 16 + i] + (T)rep * 1e-9; wi[c] = (4 * q + c == i) ? 1.0 : 0.0; }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int kq = k >> 2, kc = k & 3;
             T lraw, y[4], r;
+            if (V == 15) { // V14 with the inverse (W = L^-1) carried by the SAME wave: the update of pivot k - 1 fills the wait for the
+                           // exchange of pivot k (its multiplier is the wave's own register, row k - 1 of W a DPP row broadcast)
+                colx4[q][i] = a[kc];
+                asm volatile("" ::: "memory");
+                lraw = colx4[kq][i];
+#pragma unroll
+                for (int c = 0; c < 4; c++) y[c] = colx4[kq][4 * q + c];
+                asm volatile("" ::: "memory");
+                if (k > 0) {
+                    *((q == ((k - 1) >> 2)) ? &Ad[k - 1][i] : junk) = lprev;
+                    T wk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wk[c] = ba_rowbcast_k(wi[c], k - 1);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wi[c] -= lprev * wk[c];
+                }
+                asm volatile("" ::: "memory");
+                const T dk = ba_readlane(a[kc], 16 * kq + k);
+                r = ba_rcp(dk);
+                __builtin_amdgcn_sched_barrier(0);
+                const T lm = (i > k) ? lraw : (T)0;
+                const T l = lm * r;
+#pragma unroll
+                for (int c = 0; c < 4; c++) a[c] -= l * y[c];
+                lprev = l;
+                continue;
+            }
             if (V >= 13) { // V11 with the L / progress stores of pivot k - 1 issued BEHIND the exchange loads of pivot k
                 colx4[q][i] = a[kc];
                 asm volatile("" ::: "memory");
@@ -182,7 +209,7 @@ template <int V> __global__ __launch_bounds__(256) void probe(long long *out, do
             ba_wave_lds_sync();
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc += a[c];
+        for (int c = 0; c < 4; c++) acc += a[c] + wi[c];
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     sink[lane] = acc;
@@ -378,9 +405,9 @@ int main()
     hipMalloc(&tile, 2048); hipMalloc(&sink, 4096); hipMalloc(&d, 64);
     hipMemcpy(tile, h.data(), 2048, hipMemcpyHostToDevice);
     const int reps = 2000;
-    const char *names[] = {"V0 wave-0 loop as shipped", "V1 no L/progress stores", "V2 V1 with ONE Newton step", "V3 V1 without the LDS exchange", "V4 V1 without readlane/rcp", "V5 DPP row + bpermute column", "V6 V5 without L/progress stores", "V7 V5 hand-ordered, stores deferred", "V8 V7 without L/progress stores", "V9 row swaps + DPP, stores deferred", "V10 V9 without L/progress stores", "V11 V0, compiler-only ordering", "V12 V11 without L/progress stores", "V13 V11, stores behind next loads", "V14 V13, Newton before the load wait"};
+    const char *names[] = {"V0 wave-0 loop as shipped", "V1 no L/progress stores", "V2 V1 with ONE Newton step", "V3 V1 without the LDS exchange", "V4 V1 without readlane/rcp", "V5 DPP row + bpermute column", "V6 V5 without L/progress stores", "V7 V5 hand-ordered, stores deferred", "V8 V7 without L/progress stores", "V9 row swaps + DPP, stores deferred", "V10 V9 without L/progress stores", "V11 V0, compiler-only ordering", "V12 V11 without L/progress stores", "V13 V11, stores behind next loads", "V14 V13, Newton before the load wait", "V15 V14 + inverse in the same wave"};
 #define RUN(V, TH) hipLaunchKernelGGL(probe<V>, dim3(1), dim3(TH), 0, 0, d, sink, tile, reps); hipDeviceSynchronize(); hipMemcpy(&t, d, 8, hipMemcpyDeviceToHost); printf("%-36s (%3d threads): %.1f cycles per pivot\n", names[V], TH, t / (double)reps / 16);
-    RUN(0, 64) RUN(0, 256) RUN(1, 64) RUN(2, 64) RUN(3, 64) RUN(4, 64) RUN(5, 64) RUN(6, 64) RUN(7, 64) RUN(8, 64) RUN(9, 64) RUN(10, 64) RUN(11, 64) RUN(12, 64) RUN(13, 64) RUN(14, 64)
+    RUN(0, 64) RUN(0, 256) RUN(1, 64) RUN(2, 64) RUN(3, 64) RUN(4, 64) RUN(5, 64) RUN(6, 64) RUN(7, 64) RUN(8, 64) RUN(9, 64) RUN(10, 64) RUN(11, 64) RUN(12, 64) RUN(13, 64) RUN(14, 64) RUN(15, 64)
     long long t4[4];
 #define RUN2(W, M, label) hipLaunchKernelGGL((probe2<W, M>), dim3(1), dim3(256), 0, 0, d, sink, tile, reps); hipDeviceSynchronize(); hipMemcpy(t4, d, 32, hipMemcpyDeviceToHost); printf("%-52s: wave 0 %.1f, wave %d %.1f cycles per pivot\n", label, t4[0] / (double)reps / 16, W, t4[W] / (double)reps / 16);
     RUN2(1, 1, "look-ahead factor wave alone (no L stores)")

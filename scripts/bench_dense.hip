@@ -146,8 +146,7 @@ int main(int argc, char **argv)
         printf("fused step p=8: own work inside the four A1 phases (before their barriers), waves 0..3: %lld %lld %lld %lld\n", hf[6], hf[14], hf[22], hf[30]);
         long long ho[16]; CK(hipMemcpyFromSymbol(ho, HIP_SYMBOL(ba_stamp_own), sizeof(ho)));
         { long long hp[16]; CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(ba_stamp_piv), sizeof(hp)));
-          for (int ph = 0; ph < 4; ph++) printf("fused step p=8: factor wave, phase %d: tile in registers at %lld, fifteen pivots done at %lld; inverse wave done at %lld\n", ph, hp[4 * ph], hp[4 * ph + 1], hp[4 * ph + 2]); }
-        { int sp[16]; CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(ba_stamp_spin), sizeof(sp))); printf("fused step p=8: inverse wave, phase 2, failed polls per pivot:"); for (int k = 0; k < 15; k++) printf(" %d", sp[k]); printf("\n"); }
+          for (int ph = 0; ph < 4; ph++) printf("fused step p=8: factor wave, phase %d: tile in registers at %lld, fifteen pivots done at %lld\n", ph, hp[4 * ph], hp[4 * ph + 1]); }
         for (int w = 0; w < 4; w++) printf("fused step p=8: wave %d own work per pivot-loop phase: %lld %lld %lld %lld\n", w, ho[4 * w], ho[4 * w + 1], ho[4 * w + 2], ho[4 * w + 3]);
     }
     for (int w = 0; w < 4; w++)
