@@ -199,11 +199,16 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // (only in the one-workgroup-per-CU variant: the 64 registers would push the other one over 256 = one wave per SIMD)
     T t16a[NB / 4], t16b[NB / 4];
     if (INL && Wprev && wv < 2) {
+        // (addresses by pointer increments: one 64-bit multiply per operand instead of one per load -- v_mad_i64_i32 is slow, and
+        // these sit in front of the first loads of the kernel)
+        const T *pa = S + (size_t)(p0 - NB + lk) * ld + p0 + li, *pb = Wprev + (size_t)lk * ld + p0 + 16 * wv + li;
+        const size_t kstep = 4 * (size_t)ld;
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
-            t16a[kk] = S[(size_t)(p0 - NB + 4 * kk + lk) * ld + p0 + li]; // (negated at use: a sign flip here makes the compiler
-                                                                          // wait for every older load before it issues the next)
-            t16b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * wv + li];
+            t16a[kk] = *pa; // (negated at use: a sign flip here makes the compiler wait for every older load before it issues the next)
+            t16b[kk] = *pb;
+            pa += kstep;
+            pb += kstep;
         }
     }
     if (tid < NB) dinv[tid] = (T)0;
@@ -223,10 +228,14 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // 1 and 2 (every later barrier waits for those stores, and the GEMM at the end reads them past L1).
     auto tile16_load = [&](int ti, int tj, T (&a)[NB / 4], T (&b)[NB / 4]) {
         const int pp = p0 - NB;
+        const T *pa = S + (size_t)(pp + lk) * ld + p0 + 16 * tj + li, *pb = Wprev + (size_t)lk * ld + p0 + 16 * ti + li;
+        const size_t kstep = 4 * (size_t)ld;
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
-            a[kk] = S[(size_t)(pp + 4 * kk + lk) * ld + p0 + 16 * tj + li]; // A[j][k] = L[j][k] (negated at use)
-            b[kk] = Wprev[(size_t)(4 * kk + lk) * ld + p0 + 16 * ti + li];   // B[k][i] = Y[i][k]
+            a[kk] = *pa; // A[j][k] = L[j][k] (negated at use)
+            b[kk] = *pb; // B[k][i] = Y[i][k]
+            pa += kstep;
+            pb += kstep;
         }
     };
     auto tile16_apply = [&](int ti, int tj, const T (&a)[NB / 4], const T (&b)[NB / 4]) {
@@ -363,7 +372,10 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 const T dk = ba_readlane(a[kc], 16 * kq + k); // pivot: lane (i = k, q = kq)
                 const T r = ba_rcp(dk);
                 __builtin_amdgcn_sched_barrier(0);
-                const T lm = (i > k) ? lraw : (T)0;
+                int iv = i; // (opaque copy: the comparison is made here, one v_cmp off the critical path; hoisted in front of the
+                            // sub-panel loop the fifteen lane masks cost thirty SGPRs, their spills and a start-up delay for every wave)
+                asm volatile("" : "+v"(iv));
+                const T lm = (iv > k) ? lraw : (T)0;
                 const T l = lm * r;
 #pragma unroll
                 for (int c = 0; c < 4; c++) a[c] -= l * y[c]; // columns <= k are dead from here on
@@ -520,6 +532,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // (0 and 3 or 1 and 2: 20 MFMAs either way).
     const int r0 = HALVES ? p0 + NB + 64 * rblk + 32 * (blk & 1) + 16 * (wv & 1) : p0 + NB + 64 * blk + 16 * wv;
     if (r0 >= nrows || nb < NB) return;
+    const T *const px = S + (size_t)(p0 + lk) * ld + r0 + li; // X[n][k] at px[k / 4 * 4 ld]
     if constexpr (!HALVES) {
         acc_t acc[4];
 #pragma unroll
@@ -530,7 +543,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) // B[k][n] = X[n][k]; agent-scope load = sc1, served by L2: this CU's L1 may hold
                                             // the pre-update lines
-            xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xall[kk] = __hip_atomic_load(px + kk * (4 * (size_t)ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++) {
@@ -558,7 +571,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         T xall[NB / 4];
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++)
-            xall[kk] = __hip_atomic_load(&S[(size_t)(p0 + 4 * kk + lk) * ld + r0 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xall[kk] = __hip_atomic_load(px + kk * (4 * (size_t)ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_sched_barrier(0);
         auto rowgemm = [&](auto tiles) { // tiles: the two column tiles of this wave (compile-time list)
             constexpr int NT = decltype(tiles)::n;
