@@ -383,8 +383,9 @@ template <typename T> struct Solver final : SolverBase {
                 int nupd = 0;
                 for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
                 // Up to D ~ 3000 the panel is the critical path: the variant with the look-ahead update inlined into the
-                // sub-panel loop (~250 VGPRs, one workgroup per CU, so a panel workgroup never shares its CU with an update
-                // workgroup).  Beyond, the update dominates: out-of-line variant, 116 VGPRs + < 80 KiB LDS = two per CU.
+                // sub-panel loop (one workgroup per CU by its dynamic-LDS request, so a panel workgroup never shares its CU
+                // with an update workgroup).  Beyond, the update dominates: out-of-line variant, <= 256 registers + < 80 KiB
+                // LDS = two per CU (tests/test_kernel_resources.py pins that).
                 if (nblk < 48) {
                     const int nq = below > 0 ? npanel : 0; // workgroups that update the panel workgroups' rows (see k_ldlt_step)
                     const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
