@@ -27,7 +27,7 @@ EXPORTS = [
     "ba_solver_create", "ba_solver_free", "ba_solver_set_allreduce", "ba_solver_set_stream", "ba_solver_shard",
     "ba_minimize", "ba_solver_linearize", "ba_solver_try_step", "ba_solver_accept", "ba_solver_stats", "ba_solver_get",
     "ba_solver_keep_intermediates", "ba_solver_set_state", "ba_solver_timing", "ba_solver_time_phase", "ba_device_info",
-    "ba_version", "ba_shard_plan", "ba_problem_save_cache", "ba_problem_load_cache",
+    "ba_version", "ba_shard_plan", "ba_problem_save_cache", "ba_problem_load_cache", "ba_solver_selftest",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
         L.ba_minimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ba_solver_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ba_solver_time_phase.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        L.ba_solver_selftest.argtypes = [C.c_void_p, C.c_int]
         L.ba_problem_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.ba_problem_get.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.ba_problem_load_bal.argtypes = [C.c_char_p, C.c_void_p]
@@ -283,6 +284,10 @@ class Solver:
         ms = C.c_double()
         _chk(lib().ba_solver_time_phase(self._h, phase, reps, float(lam), C.byref(ms)), "ba_solver_time_phase")
         return ms.value
+
+    def selftest(self, which):
+        """Returns the library's return code (not raised): the failure paths are what this hook exists to show."""
+        return int(lib().ba_solver_selftest(self._h, int(which)))
 
     # -- multi-GPU plumbing -------------------------------------------------------------------------------
     def set_stream(self, raw_stream):

@@ -56,6 +56,11 @@ __device__ __forceinline__ float ba_rcp(float d)
 }
 
 #define BA_NB 64
+// Bounds of the in-launch hand-off waits (a wait that runs out is an ERROR, reported through the device error word).
+#define BA_FLAG_SPINS (1 << 22)
+#define BA_SWEEP_SPINS (1 << 24)
+#define BA_DEVERR_ROW_FLAG 1 /* k_ldlt_step: a panel workgroup never saw its rows' look-ahead update announced */
+#define BA_DEVERR_SWEEP 2    /* k_ldlt_backflow: an unknown of a later group was never published */
 
 // compile-time list of (up to four) tile indices
 template <int N, int T0, int T1, int T2, int T3> struct ba_tiles {
@@ -172,7 +177,7 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                               T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel,
-                                              const int *flags = nullptr, int epoch = 0)
+                                              const int *flags = nullptr, int epoch = 0, T *errw = nullptr)
 {
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
@@ -453,8 +458,13 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // finished long ago; a wave with time to spare makes sure here, so that the L2 round trip of the check is not
                 // in front of the row GEMM -- every wave reads the rows behind the barriers that follow
                 int spins = 0;
-                while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22))
+                while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < BA_FLAG_SPINS)
                     __builtin_amdgcn_s_sleep(4);
+                // pairs with the release store of the row workgroup (k_ldlt_step): its rows are visible behind this fence
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // A wait that ran out means the row GEMM below would read rows without their update: the factor would be finite
+                // and wrong.  Loud instead: the error word travels to the host with the scalars of the trial (BA_ERR_HIP).
+                if (spins >= BA_FLAG_SPINS && errw) __hip_atomic_store(errw, (T)BA_DEVERR_ROW_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (s == 3) {
                 // ... and the sums of row 3, which do not need W_33 (being built by wave 1 right now): only the three
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 template <typename T, int NB, bool INL>
 __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
                                                    T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
-                                                   int nq = 0, int *__restrict__ flags = nullptr)
+                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr)
 {
     int bid = blockIdx.x;
     if (INL && bid < nq) {
@@ -643,12 +653,13 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
         ba_update_quad<T, NB, false, true>(ld, p0 - NB, rown, p0, false, S, Wprev, nullptr, threadIdx.x >> 6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&flags[rown / NB], p0 / NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release: the tile's (write-through) stores of every wave, ordered by the barrier above, are visible at agent scope before the flag
+        if (threadIdx.x == 0) __hip_atomic_store(&flags[rown / NB], p0 / NB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (INL) bid -= nq;
     if (bid < npanel) {
-        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, INL ? flags : nullptr, p0 / NB);
+        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, INL ? flags : nullptr, p0 / NB, errw);
         return;
     }
     // tile u of the set {(ti, tj): 1 <= tj <= ti, tj < ntc}, rows p0 + 64 ti, columns p0 + 64 tj
@@ -919,11 +930,13 @@ __global__ void k_fill_sentinel(int n, T *__restrict__ x)
 
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zrow, int nblk, T *__restrict__ S, const T *__restrict__ Winv,
-                                                       T *__restrict__ x)
+                                                       T *__restrict__ x, T *__restrict__ errw = nullptr, int spin_limit = BA_SWEEP_SPINS,
+                                                       int skip_group = -1 /* self-test only: this group never publishes */)
 {
     static_assert(NB == 64, "written for 64-wide block columns");
     __shared__ T zs[2 * NB], xin[2 * NB], xs[2 * NB], part[4][NB], part2[2][2 * NB];
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    if (g == skip_group) return;
     const bool odd = (nblk & 1) != 0;
     const int fb = odd ? max(0, 2 * g - 1) : 2 * g, nbg = (odd && g == 0) ? 1 : 2; // first block column / block columns of this group
     const int c0 = fb * NB, ncg = nbg * NB;
@@ -962,7 +975,9 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
             if (r0 + tid < ncols) {
                 int spins = 0;
                 do xv = __hip_atomic_load(&x[r0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (ba_is_sentinel(xv) && ++spins < (1 << 24));
+                while (ba_is_sentinel(xv) && ++spins < spin_limit);
+                // never published: the sweep would go on with the sentinel (a NaN) -- report it instead of a silently rejected step
+                if (ba_is_sentinel(xv) && errw) __hip_atomic_store(errw, (T)BA_DEVERR_SWEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             xin[tid] = xv;
         }
@@ -1009,12 +1024,58 @@ template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t
 // max_groups: how many workgroups of k_ldlt_backflow are certainly resident at once (one per CU is a safe count; they
 // wait for each other, so a grid beyond that falls back to a launch per pair of block columns).
 template <typename T, int NB>
-inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false, int max_groups = 256)
+inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false, int max_groups = 256,
+                              T *errw = nullptr)
 {
     const int nblk = (ncols + NB - 1) / NB, groups = (nblk + 1) / 2;
     if (groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
     if (!armed) hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
-    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x);
+    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x, errw, (int)BA_SWEEP_SPINS);
+}
+
+// Host side of the factorisation on `st`: one k_ldlt_panel launch for the first block column, then one fused k_ldlt_step per
+// block column (or panel + update launches for a single block column).  flags: nflags ints (hand-off flags of the row
+// workgroups), Wp: 2 * ld * NB (double-buffered Y = L D panel), Winv: one NB x NB inverse per block column.
+template <typename T, int NB>
+inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr)
+{
+    const int nblk = (ncols + NB - 1) / NB;
+    const size_t wsz = (size_t)ld * NB;
+    for (int p = 0; p < nblk; p++) {
+        const int p0 = p * NB;
+        const int below = nrows - (p0 + NB);
+        const int npanel = below > 0 ? (below + 63) / 64 : 1;
+        T *wcur = Wp + (size_t)(p & 1) * wsz, *wprev = Wp + (size_t)((p + 1) & 1) * wsz;
+        // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
+        // and keeps the previous panel's update off the diagonal block's path.
+        const bool fused = nblk >= 2;
+        if (p == 0 || !fused) {
+            hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp,
+                               Winv + (size_t)p * NB * NB, flags, nflags);
+            const int p1 = p0 + NB;
+            if (!fused && p1 < ncols) {
+                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
+            }
+        } else {
+            // trailing tiles of block column p0 - 64 outside block column p0: rows p0 + 64 ti, cols p0 + 64 tj, 1 <= tj <= ti
+            const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
+            int nupd = 0;
+            for (int ti = 1; ti < nt; ti++) nupd += ti < ntc - 1 ? ti : ntc - 1;
+            // Up to D ~ 3000 the panel is the critical path: the variant with the look-ahead update inlined into the
+            // sub-panel loop (one workgroup per CU by its dynamic-LDS request, so a panel workgroup never shares its CU
+            // with an update workgroup).  Beyond, the update dominates: out-of-line variant, <= 256 registers + < 80 KiB
+            // LDS = two per CU (tests/test_kernel_resources.py pins that).
+            if (nblk < 48) {
+                const int nq = below > 0 ? npanel : 0;      // workgroups that update the panel workgroups' rows (see k_ldlt_step)
+                const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
+                hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2, S, wcur,
+                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw);
+            } else
+                hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, S, wcur,
+                                   wprev, Winv + (size_t)p * NB * NB, 0, (int *)nullptr, errw);
+        }
+    }
 }
 
 // The same with one launch per pair of block columns (k_ldlt_backpair): no workgroup waits for another.

@@ -53,6 +53,10 @@ static int validate(const ba_problem *p)
     if (p->N <= 0 || p->M <= 0 || p->K <= 0) return BA_ERR_ARG;
     for (int i = 0; i < p->K; i++)
         if (p->cam_idx[i] < 0 || p->cam_idx[i] >= p->N || p->pt_idx[i] < 0 || p->pt_idx[i] >= p->M) return BA_ERR_PARSE;
+    // strtod accepts "nan" / "inf" tokens; a non-finite measurement or parameter would poison every sum on the device
+    for (double v : p->meas) if (!std::isfinite(v)) return BA_ERR_PARSE;
+    for (double v : p->cams9) if (!std::isfinite(v)) return BA_ERR_PARSE;
+    for (double v : p->pts) if (!std::isfinite(v)) return BA_ERR_PARSE;
     return BA_OK;
 }
 
@@ -86,6 +90,7 @@ int ba_problem_load_bal(const char *path, ba_problem **out)
     for (long k = 0; k < K && ok; k++) {
         long a = 0, b = 0;
         ok = next_int(a) && next_int(b) && next_dbl(p->meas[2 * (size_t)k]) && next_dbl(p->meas[2 * (size_t)k + 1]);
+        if (a < 0 || a >= N || b < 0 || b >= M) ok = false; // checked as long: 4294967296 must not wrap into a valid index
         p->cam_idx[k] = (int)a; p->pt_idx[k] = (int)b;
     }
     for (size_t i = 0; i < p->cams9.size() && ok; i++) ok = next_dbl(p->cams9[i]);

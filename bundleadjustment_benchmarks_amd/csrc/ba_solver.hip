@@ -34,7 +34,8 @@ constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 
 constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
        SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
-       SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */ };
+       SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */,
+       SC_ERR = 14 /* device error word: a BA_DEVERR_* code written by a kernel whose in-launch hand-off wait ran out */ };
 enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_L0B, EV_L1B /* linearisation, one pair per buffer */, EV_F, EV_N };
 
 template <typename T> struct DevBuf {
@@ -70,6 +71,7 @@ struct SolverBase {
     virtual void set_stream_hook() {}
     virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
     virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
+    virtual int selftest(int which) = 0;
     ba_allreduce_fn ar_fn = nullptr;
     void *ar_user = nullptr;
     hipStream_t st = nullptr;
@@ -228,7 +230,20 @@ template <typename T> struct Solver final : SolverBase {
     {
         HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, sizeof(T) * NSCAL, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        return BA_OK;
+        return check_device_error();
+    }
+
+    // The device error word (SC_ERR) of the scalars just read: a kernel's bounded wait for another workgroup of its launch ran
+    // out (k_ldlt_step's row-update flag, k_ldlt_backflow's sentinel poll), so the step is garbage.  Loud, and cleared for the next call.
+    int check_device_error()
+    {
+        if (h_scal[SC_ERR] == (T)0) return BA_OK;
+        fprintf(stderr, "ba_mi355x: device error %d: %s\n", (int)h_scal[SC_ERR],
+                (int)h_scal[SC_ERR] == BA_DEVERR_ROW_FLAG ? "k_ldlt_step: the look-ahead update of a row block was never announced"
+                                                          : "k_ldlt_backflow: an unknown of the backward sweep was never published");
+        h_scal[SC_ERR] = 0;
+        (void)hipMemsetAsync(d_scal.p + SC_ERR, 0, sizeof(T), st);
+        return BA_ERR_HIP;
     }
 
     double ev_ms(int a, int b)
@@ -356,52 +371,10 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
 
-    void launch_factor()
-    {
-        const int nrows = D + 1, ncols = D;
-        const int nblk = (ncols + NB - 1) / NB;
-        const size_t wsz = (size_t)ld * NB;
-        for (int p = 0; p < nblk; p++) {
-            const int p0 = p * NB;
-            const int below = nrows - (p0 + NB);
-            const int npanel = below > 0 ? (below + 63) / 64 : 1;
-            T *wcur = d_Wp.p + (size_t)(p & 1) * wsz, *wprev = d_Wp.p + (size_t)((p + 1) & 1) * wsz;
-            // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
-            // and keeps the previous panel's update off the diagonal block's path.
-            const bool fused = nblk >= 2;
-            if (p == 0 || !fused) {
-                hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p,
-                                   fused ? wcur : d_Wp.p, d_Winv.p + (size_t)p * NB * NB, d_flags.p, (int)d_flags.n);
-                const int p1 = p0 + NB;
-                if (!fused && p1 < ncols) {
-                    const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
-                    hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, d_Wp.p);
-                }
-            } else {
-                // trailing tiles of block column p0 - 64 outside block column p0: rows p0 + 64 ti, cols p0 + 64 tj, 1 <= tj <= ti
-                const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
-                int nupd = 0;
-                for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                // Up to D ~ 3000 the panel is the critical path: the variant with the look-ahead update inlined into the
-                // sub-panel loop (one workgroup per CU by its dynamic-LDS request, so a panel workgroup never shares its CU
-                // with an update workgroup).  Beyond, the update dominates: out-of-line variant, <= 256 registers + < 80 KiB
-                // LDS = two per CU (tests/test_kernel_resources.py pins that).
-                if (nblk < 48) {
-                    const int nq = below > 0 ? npanel : 0; // workgroups that update the panel workgroups' rows (see k_ldlt_step)
-                    const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
-                    hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2,
-                                       d_S.p, wcur, wprev, d_Winv.p + (size_t)p * NB * NB, nq, d_flags.p);
-                }
-                else
-                    hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, d_S.p,
-                                   wcur, wprev, d_Winv.p + (size_t)p * NB * NB);
-            }
-        }
-    }
+    void launch_factor() { ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR); }
 
-    // backward sweep, one launch per block column (a 4-column window with thread-per-column dot products was
-    // measured slower: the column reads are uncoalesced across lanes)
-    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true, num_cus); }
+    // backward sweep: one data-flow launch (k_ldlt_backflow) while its groups are certainly co-resident
+    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR); }
 
     void launch_post_reduce()
     {
@@ -468,6 +441,7 @@ template <typename T> struct Solver final : SolverBase {
                 if ((rc = linearize_enqueue(false, 1 - cur))) return rc;
                 HIPCHK(hipEventSynchronize(ev[EV_F]));
                 for (int i = 0; i < NSCAL; i++) h_scal[i] = h_pin[i];
+                if ((rc = check_device_error())) return rc;
             } else if ((rc = fetch_scalars())) return rc;
             HIPCHK(hipGetLastError());
             tm.trial_ms += ev_ms(EV_T0, EV_T6);
@@ -760,6 +734,20 @@ template <typename T> struct Solver final : SolverBase {
         return rc;
     }
 
+    // which = 1: the backward sweep with the group at the head of its chain missing (and a short spin bound): the groups behind
+    // it wait for unknowns that are never published -- the production path's reaction to that must be BA_ERR_HIP.
+    int selftest(int which) override
+    {
+        if (which != 1) return BA_ERR_ARG;
+        const int nblk = (D + NB - 1) / NB, groups = (nblk + 1) / 2;
+        if (groups < 2 || groups > num_cus) return BA_ERR_ARG;
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, Dp, d_dxc.p);
+        hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, D, ld, D, nblk, d_S.p, d_Winv.p, d_dxc.p,
+                           d_scal.p + SC_ERR, 1 << 10, groups - 1);
+        have_step = false;
+        return fetch_scalars();
+    }
+
     int time_phase(int phase, int reps, double lambda_d, double *ms) override
     {
         if (reps < 1 || !ms) return BA_ERR_ARG;
@@ -919,5 +907,7 @@ int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, doubl
 {
     return s ? s->impl->time_phase(phase, reps, lambda, ms_per_launch) : BA_ERR_ARG;
 }
+
+int ba_solver_selftest(ba_solver *s, int which) { return s ? s->impl->selftest(which) : BA_ERR_ARG; }
 
 } // extern "C"

@@ -193,6 +193,13 @@ int ba_solver_timing(ba_solver *s, ba_timing *out, int reset);
  * 6 dense factorisation only, 7 backward sweep only (6 / 7 rebuild S untimed before every repetition). */
 int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, double *ms_per_launch);
 
+/* Test hook for the failure paths of the in-launch hand-offs (no reference counterpart).  which = 1: runs the one-launch
+ * backward sweep with the workgroup at the head of its dependency chain missing and a short spin bound, so the others
+ * wait for unknowns that are never published.  Returns what the production path returns for that: BA_ERR_HIP (the kernels
+ * raise a device error word that is read back with the trial's scalars); BA_ERR_ARG when the reduced system has fewer than
+ * four 64-wide block columns (a single group has nobody to wait for). */
+int ba_solver_selftest(ba_solver *s, int which);
+
 /* Library / device info: fills name (<= n bytes), returns the number of CUs via *cus. */
 int ba_device_info(int device, char *name, size_t n, int *cus);
 const char *ba_version(void);

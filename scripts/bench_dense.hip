@@ -46,21 +46,14 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < reps + 1; rep++) {
         CK(hipMemcpyAsync(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
-        for (int p = 0; p < nblk; p++) {
+        if (fused) ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags); // the product's launch sequence
+        else for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
-            double *wcur = Wp + (size_t)(p & 1) * ld * NB, *wprev = Wp + (size_t)((p + 1) & 1) * ld * NB;
-            if (p == 0 || !fused) {
-                hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp, Winv + (size_t)p * NB * NB, flags, nflags);
-                const int p1 = p0 + NB;
-                if (!fused && p1 < ncols) {
-                    const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
-                    hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
-                }
-            } else {
-                const int nt = (nrows - p0 + 63) / 64, ntc = (ncols - p0 + 63) / 64;
-                int nupd = 0;
-                for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
-                if (nblk < 48) { const int nq = below > 0 ? g : 0, g2 = below > 0 ? 2 * g : 1; hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(nq + g2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, g2, S, wcur, wprev, Winv + (size_t)p * NB * NB, nq, flags); } else hipLaunchKernelGGL((k_ldlt_step<double, NB, false>), dim3(g + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, g, S, wcur, wprev, Winv + (size_t)p * NB * NB);
+            hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB, flags, nflags);
+            const int p1 = p0 + NB;
+            if (p1 < ncols) {
+                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                hipLaunchKernelGGL((k_ldlt_update<double, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp);
             }
         }
         CK(hipEventRecord(e1, st));

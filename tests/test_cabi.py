@@ -69,6 +69,15 @@ def test_loader_errors(ba, tmp_path):
     with pytest.raises(ba.BAError) as e:
         ba.Problem.load_bal(str(oob))
     assert e.value.code == 3
+    # an index that would wrap into a valid int (2^32) and non-finite tokens (strtod accepts them) are refused
+    for name, text in (("wrap.txt", "1 1 1\n4294967296 0 1.0 2.0\n" + "0.0\n" * 12),
+                       ("nan.txt", "1 1 1\n0 0 nan 2.0\n" + "0.0\n" * 12),
+                       ("inf.txt", "1 1 1\n0 0 1.0 2.0\n" + "0.0\n" * 11 + "inf\n")):
+        f = tmp_path / name
+        f.write_text(text)
+        with pytest.raises(ba.BAError) as e:
+            ba.Problem.load_bal(str(f))
+        assert e.value.code == 3, name
 
 
 def test_save_load_round_trip_and_unsorted_input(ba, tmp_path):
