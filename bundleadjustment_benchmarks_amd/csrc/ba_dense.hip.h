@@ -28,16 +28,7 @@
 
 #include <hip/hip_runtime.h>
 
-typedef double ba_d4 __attribute__((ext_vector_type(4)));
-typedef float ba_f4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct ba_acc;
-template <> struct ba_acc<double> { typedef ba_d4 type; };
-template <> struct ba_acc<float> { typedef ba_f4 type; };
-
-__device__ __forceinline__ ba_d4 ba_mfma(double a, double b, ba_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ ba_f4 ba_mfma(float a, float b, ba_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-template <typename T> __device__ __forceinline__ int ba_crow(int lk, int v) { return sizeof(T) == 8 ? lk + 4 * v : 4 * lk + v; }
+#include "ba_mfma.hip.h"
 
 // 1/d to (nearly) full precision: hardware estimate + two Newton steps (the division expansion would sit on the
 // critical path of every pivot).

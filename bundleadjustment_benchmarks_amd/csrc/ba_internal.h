@@ -43,7 +43,7 @@ struct ba_structure {
     std::vector<int> pair_hi, pair_lo;
     long long E = 0;                  // entries
     std::vector<int> ent_r, ent_c;    // row / column observation (local index) per entry, grouped by pair
-    int chunk_len = 32;
+    int chunk_len = 64;
     int nchunks = 0;
     std::vector<int> chunk_ptr;       // nchunks + 1 offsets into entries
     std::vector<int> chunk_pair;      // pair id per chunk
@@ -56,6 +56,7 @@ struct ba_structure {
     std::vector<int> cam_obs;         // Kl observations grouped by camera
 };
 
-int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int chunk_len, ba_structure *out);
+// chunk_len: entries per chunk of a camera pair (one wavefront of k_schur_pairs); dchunk_len: observations per chunk of a camera (k_cam_gram)
+int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int chunk_len, int dchunk_len, ba_structure *out);
 
 #endif

@@ -4,7 +4,7 @@
 //   cam   T[15][N]   SoA  R row-major (9), T (3), f = K(0,0), k1, k2       (state, x and xTest copies)
 //   pts   T[3][Ml]   SoA
 //   meas  T[2][Kl], r T[2][Kl], Jc T[18][Kl] (2x9 row-major per obs), Jp T[6][Kl]   SoA over observations
-//   rec   T[Kl][40]  AoS  per observation: Z (9x3 row-major), zt = Z (dinv o t), dinv of its point -- gathered by the pair kernel
+//   rec   T[Kl][32]  AoS  per observation: Z (9x3 row-major), dinv of its point -- two 128-byte lines (fp64), gathered by the pair kernel
 //   U0 T[6][Ml], gp T[3][Ml], dinv T[3][Ml], tvec T[3][Ml], tri T[6][Ml]            per point
 //   S     T[Dp][Dp]  column-major, lower triangle + augmented rows D (rhs), D+1 (g_c), D+2 (scalars)
 #ifndef BA_KERNELS_HIP_H
@@ -12,8 +12,12 @@
 
 #include <hip/hip_runtime.h>
 
-#define BA_REC 40 /* Z (27), zt (9), dinv of the point (3), pad (1): 320 B, 16-byte aligned */
+#include "ba_mfma.hip.h"
+
+#define BA_REC 32 /* Z (27), dinv of the point (3), pad (2): 256 B = two cache lines in fp64, one in fp32 */
+#define BA_REC_DINV 27
 #define BA_SLAB 96
+#define BA_CHUNK 64 /* entries of one camera pair per chunk = per wavefront of the pair kernel */
 #define BA_EPS_PSI 1e-15 /* src/Optimization/BAFunctor.h:159 */
 
 __device__ __forceinline__ double tsqrt(double x) { return sqrt(x); }
@@ -372,16 +376,14 @@ __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__r
         Bt[3 * rr + 1] = b1 - l10 * Bt[3 * rr];
         Bt[3 * rr + 2] = b2 - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
     }
-    const T td0 = i0 * t0, td1 = i1 * t1, td2 = i2 * t2;
     T *o = rec + (size_t)i * BA_REC;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
         const T z0 = a0 * Bt[0] + a1 * Bt[3], z1 = a0 * Bt[1] + a1 * Bt[4], z2 = a0 * Bt[2] + a1 * Bt[5];
         o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
-        o[27 + c] = z0 * td0 + z1 * td1 + z2 * td2;
     }
-    o[36] = i0; o[37] = i1; o[38] = i2;
+    o[BA_REC_DINV] = i0; o[BA_REC_DINV + 1] = i1; o[BA_REC_DINV + 2] = i2;
 }
 
 // ---- K4 (QRCHOL / QRKIT left block): Householder QR of [sqrt(lambda) I3 ; (Jp)_j] per point ------------------
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
         tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
         tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
     }
-    // Z_i = A_i^T Q1_i (9x3), zt_i = Z_i t
+    // Z_i = A_i^T Q1_i (9x3)
     if (gid < npts) {
 #pragma unroll
         for (int s = 0; s < SL; s++) {
@@ -498,9 +500,8 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
                 const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
                 const T z0 = a0 * Q[s][0] + a1 * Q[s][3], z1 = a0 * Q[s][1] + a1 * Q[s][4], z2 = a0 * Q[s][2] + a1 * Q[s][5];
                 o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
-                o[27 + c] = z0 * q1[0] + z1 * q1[1] + z2 * q1[2];
             }
-            o[36] = 1; o[37] = 1; o[38] = 1;
+            o[BA_REC_DINV] = 1; o[BA_REC_DINV + 1] = 1; o[BA_REC_DINV + 2] = 1;
         }
     }
 }
@@ -571,54 +572,147 @@ __global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__
         const T z0 = a0 * QR[0][0] + a1 * QR[1][0] + a2 * QR[2][0], z1 = a0 * QR[0][1] + a1 * QR[1][1] + a2 * QR[2][1],
                 z2 = a0 * QR[0][2] + a1 * QR[1][2] + a2 * QR[2][2];
         o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
-        o[27 + c] = z0 * t[0] + z1 * t[1] + z2 * t[2];
     }
-    o[36] = 1; o[37] = 1; o[38] = 1;
+    o[BA_REC_DINV] = 1; o[BA_REC_DINV + 1] = 1; o[BA_REC_DINV + 2] = 1;
 }
 
 // ---- K5: Schur complement / reduced camera matrix, pair-owner form -------------------------------------------
 // S_ab = delta_ab (lambda I + sum A^T A) - sum_j Z_a diag(dinv_j) Z_b^T  (src/Eigen_ext/BacktrackLevMarqQRChol.h:334-341:
 // J2bot^T J2bot; src/Eigen_ext/BacktrackLevMarqCholesky.h:274-278: the Schur complement inside the LDL^T).
-// One 32-lane group per chunk of <= chunk_len entries of one camera pair (two chunks per wavefront); lane
-// (c, q) = (sub / 3, sub % 3) owns the outputs (c, 3q .. 3q+2) of the 9x9 block.  Self entries (row observation ==
-// column observation, diagonal pairs) also accumulate the reduced-rhs term zt.  No atomics: partial blocks go to a
-// slab and are summed per pair in chunk order by k_schur_reduce.
-template <typename T>
-__global__ __launch_bounds__(256) void k_schur_chunks(int nchunks, const int *__restrict__ chunk_ptr,
-                                                      const int *__restrict__ ent_r, const int *__restrict__ ent_c,
-                                                      const T *__restrict__ rec, T *__restrict__ slab)
+//
+// For one camera pair (a, b) the sum over the points both cameras see is a contraction over (point, coordinate):
+//   [Z_a(e0) D(e0) | Z_a(e1) D(e1) | ...] (9 x 3n)  times  [Z_b(e0) | Z_b(e1) | ...]^T (3n x 9)
+// -- the one place of the assembly where the matrix cores fit: v_mfma_{f64,f32}_16x16x4 with the 9 x 9 block in the corner of
+// the 16 x 16 tile, four k-steps = 4/3 of an entry per instruction.  What it buys is not flops (a third of the tile is used) but
+// LOADS: lane (i, k) fetches exactly the A element (i, k) and the B element (k, i) it feeds to the instruction, so every Z
+// element is read once per entry (54 + 6 scalars) -- the lane-per-output form of round 1 read each of them 3 or 9 times
+// (405 loads per entry, two entries in flight, 122 us at config 4).  Column 9 of B carries t of the point for self entries (row
+// observation == column observation, diagonal pairs; the entry list holds ~point in place of the column observation), so column
+// 9 of the tile is sum Z (dinv o t), the reduced-rhs term, for free.
+//
+// The kernel is a gather: 2 records (2 cache lines each) per entry, 65 MB of records at config 4, far beyond one XCD's 4 MiB L2.
+// What keeps most of those reads in L2 is the ORDER: the chunk list is sorted by (row camera, column camera); it is cut into 8
+// bands of equal work and the workgroups with equal blockIdx % 8 -- which the dispatcher places on one XCD (observed round-robin;
+// a speed assumption only) -- walk one band front to back, all 512 wavefronts of the XCD inside a window of 512 consecutive
+// chunks = a few row cameras.  The records a row camera needs (its own, and those of the other cameras of its points) are
+// largely the ones the previous row camera needed, so they are L2 hits; HBM / Infinity Cache sees each record about once.
+//
+// One wavefront per chunk of <= 64 entries of one pair, persistent: a wavefront walks the chunks g, g + W, g + 2 W, ... of its
+// band and has the descriptor of the chunk after next and the entry indices of the next chunk in flight while it works on the
+// current one (one int4 per chunk: first entry, count | single-chunk flag, cameras hi and lo; one int2 per entry).  The entry
+// indices are handed round with ds_bpermute; the loads of eight entries (6 A + 6 dinv + 6 B per lane) are in flight while the
+// previous eight are multiplied.  A pair with a single chunk (almost all off-diagonal pairs) writes its block of S directly;
+// pairs with several chunks (diagonal pairs, heavy pairs) leave partial tiles in a slab that k_schur_reduce sums in chunk
+// order.  No atomics; the summation order is fixed by the static entry order, so the result is run-to-run reproducible.
+#define BA_CHUNK_SINGLE (1 << 16) /* flag in chunk_info.y: the only chunk of its pair */
+#define BA_NBAND 8
+struct ba_bands { int ptr[BA_NBAND + 1]; }; // chunk range of each band
+template <typename T, bool SCALED /* dinv != 1: CHOLESKY */>
+__global__ __launch_bounds__(256) void k_schur_pairs(ba_bands bands, const int4 *__restrict__ chunk_info, const int2 *__restrict__ ent,
+                                                     const T *__restrict__ rec, const T *__restrict__ tvec, int Ml, T *__restrict__ slab,
+                                                     const T *__restrict__ V, const T *__restrict__ gc, int D, int ld, T *__restrict__ S)
 {
-    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
-    const bool gok = g < nchunks;
-    const int c = sub / 3, q = sub - 3 * c;
-    const bool act = sub < 27;
-    const int e0 = gok ? chunk_ptr[g] : 0, len = gok ? chunk_ptr[g + 1] - e0 : 0;
-    // the chunk's entry indices are fetched once, one per lane, and handed round with shuffles: the per-entry
-    // loop then has a single level of dependent loads (the records), two entries in flight
-    const int ia_l = (sub < len) ? ent_r[e0 + sub] : 0, ib_l = (sub < len) ? ent_c[e0 + sub] : 0;
-    T acc0 = 0, acc1 = 0, acc2 = 0, zacc = 0;
-    const int len2 = max(len, __shfl_xor(len, 32, 64)); // the two chunks of this wavefront run in lock-step
-    for (int e = 0; e < len2; e++) {
-        const int ia = __shfl(ia_l, e, 32), ib = __shfl(ib_l, e, 32);
-        if (e < len && act) {
-            const T *ra = rec + (size_t)ia * BA_REC;
-            const T *zb = rec + (size_t)ib * BA_REC + 9 * q;
-            const T a0 = ra[3 * c] * ra[36], a1 = ra[3 * c + 1] * ra[37], a2 = ra[3 * c + 2] * ra[38];
-            acc0 += a0 * zb[0] + a1 * zb[1] + a2 * zb[2];
-            acc1 += a0 * zb[3] + a1 * zb[4] + a2 * zb[5];
-            acc2 += a0 * zb[6] + a1 * zb[7] + a2 * zb[8];
-            if (sub < 9 && ia == ib) zacc += ra[27 + sub];
+    const int lane = threadIdx.x & 63;
+    const int band = blockIdx.x % BA_NBAND;
+    const int W = (gridDim.x / BA_NBAND) * 4; // wavefronts per band (the grid is a multiple of BA_NBAND workgroups)
+    const int g1 = bands.ptr[band + 1];
+    int g = bands.ptr[band] + (blockIdx.x / BA_NBAND) * 4 + (threadIdx.x >> 6);
+    if (g >= g1) return; // (a whole wavefront leaves; the kernel has no workgroup barrier)
+    const int i = lane & 15, k = lane >> 4;
+    // k-step 4 m + k of a group of four entries (m = 0, 1, 2) belongs to entry eo[m] of the group, coordinate kc[m]
+    const int eo0 = (k == 3) ? 1 : 0, eo1 = 1 + (k >= 2 ? 1 : 0), eo2 = 2 + (k >= 1 ? 1 : 0);
+    const int kc0 = (k == 3) ? 0 : k, kc1 = (k + 1) % 3, kc2 = (k + 2) % 3;
+    const bool la = i < 9, lb = i < 10;
+    const int offa = la ? 3 * i : 0; // element (i, .) of Z_a; lanes 9..15 of a row of 16 hold zeros
+    typedef typename ba_acc<T>::type acc_t;
+    auto entry_of = [&](const int4 ci) { // this lane's entry of the chunk (lanes past the end shadow the last entry, their products are masked)
+        const int n = ci.y & 0xffff;
+        return ent[ci.x + (lane < n ? lane : n - 1)];
+    };
+    int4 ci0 = chunk_info[g];
+    int4 ci1 = chunk_info[min(g + W, g1 - 1)];
+    int2 en0 = entry_of(ci0);
+    for (; g < g1; g += W) {
+        const int2 en1 = entry_of(ci1);                          // next chunk's indices: arrive under this chunk's work
+        const int4 ci2 = chunk_info[min(g + 2 * W, g1 - 1)];     // descriptor of the chunk after next
+        const int n = ci0.y & 0xffff;
+        const int ia_l = en0.x, ib_l = en0.y;
+        acc_t acc;
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = 0;
+        constexpr int GB = 2; // groups of four entries per batch
+        T av[3 * GB], dv[3 * GB], bv[3 * GB];
+        auto fetch = [&](int t0) { // operands of the entries 4 t0 .. 4 (t0 + GB) - 1
+#pragma unroll
+            for (int u = 0; u < GB; u++) {
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    const int eo = m == 0 ? eo0 : m == 1 ? eo1 : eo2, kc = m == 0 ? kc0 : m == 1 ? kc1 : kc2;
+                    const int e = 4 * (t0 + u) + eo;
+                    const bool ok = e < n;
+                    const int es = ok ? e : n - 1;
+                    const int ia = __shfl(ia_l, es, 64), ibr = __shfl(ib_l, es, 64);
+                    const bool self = ibr < 0; // self entry: the column observation is the row observation, ibr = ~point
+                    const T *ra = rec + (size_t)ia * BA_REC;
+                    // B: column j = i of the tile: Z_b(j, kc) for j < 9; t(kc) of the point for j == 9 on a self entry
+                    const T *pb = (i < 9) ? rec + (size_t)(self ? ia : ibr) * BA_REC + 3 * i + kc
+                                          : (self ? tvec + (size_t)kc * Ml + (~ibr) : ra);
+                    const bool okb = ok && (i < 9 || (i == 9 && self));
+                    T a = 0, d = 1, b = 0;
+                    if (lb) { // (lanes 10..15 of every row of 16 issue no loads)
+                        a = ra[offa + kc];
+                        if (SCALED) d = ra[BA_REC_DINV + kc];
+                        b = *pb;
+                    }
+                    av[3 * u + m] = (ok && la) ? a : (T)0;
+                    dv[3 * u + m] = d;
+                    bv[3 * u + m] = okb ? b : (T)0;
+                }
+            }
+        };
+        const int ngroups = (n + 3) >> 2;
+        fetch(0);
+        for (int t0 = 0; t0 < ngroups; t0 += GB) {
+            T ac[3 * GB], bc[3 * GB];
+#pragma unroll
+            for (int q = 0; q < 3 * GB; q++) { ac[q] = SCALED ? av[q] * dv[q] : av[q]; bc[q] = bv[q]; }
+            if (t0 + GB < ngroups) fetch(t0 + GB); // next batch in flight under the MFMAs of this one (uniform branch)
+#pragma unroll
+            for (int q = 0; q < 3 * GB; q++) acc = ba_mfma(ac[q], bc[q], acc);
         }
-    }
-    if (gok && act) {
-        T *o = slab + (size_t)g * BA_SLAB;
-        o[9 * c + 3 * q] = acc0; o[9 * c + 3 * q + 1] = acc1; o[9 * c + 3 * q + 2] = acc2;
-        if (sub < 9) o[81 + sub] = zacc;
+        // tile element (row r, column j = i): r = ba_crow(k, v)
+        const int hi = ci0.z, lo = ci0.w;
+        if (ci0.y & BA_CHUNK_SINGLE) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int r = ba_crow<T>(k, v);
+                if (r >= 9) continue;
+                if (i < 9) {
+                    T val = -acc[v];
+                    if (hi == lo) val += V[(size_t)hi * 81 + 9 * r + i];
+                    S[(size_t)(9 * lo + i) * ld + 9 * hi + r] = val;
+                } else if (i == 9 && hi == lo) {
+                    const T gg = gc[9 * hi + r];
+                    S[(size_t)(9 * hi + r) * ld + D] = gg - acc[v];
+                    S[(size_t)(9 * hi + r) * ld + D + 1] = gg;
+                }
+            }
+        } else {
+            T *o = slab + (size_t)g * BA_SLAB;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int r = ba_crow<T>(k, v);
+                if (r >= 9) continue;
+                if (i < 9) o[9 * r + i] = acc[v];
+                else if (i == 9) o[81 + r] = acc[v];
+            }
+        }
+        ci0 = ci1; ci1 = ci2; en0 = en1;
     }
 }
 
-// Sum the chunk partials of each pair in chunk order and write the 9x9 block of S (lower block triangle; diagonal
-// blocks in full).  Row D of S receives the reduced rhs, row D+1 the camera gradient g_c (both travel through the
+// Sum the chunk partials of each pair with several chunks in chunk order and write the 9x9 block of S (lower block triangle;
+// diagonal blocks in full); pairs without any entry get their zero (or J_c^T J_c) block here too.  Row D of S receives the reduced rhs, row D+1 the camera gradient g_c (both travel through the
 // same all-reduce as S when the problem is sharded).  lambda I is added later by k_post_reduce (once, after the sum
 // over shards).
 template <typename T>
@@ -635,6 +729,7 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld,
     T s4[4] = {0, 0, 0, 0}; // four interleaved partial sums (fixed order) keep four loads in flight
     const int c1 = pair_chunk_ptr[p + 1];
     int c = pair_chunk_ptr[p];
+    if (c1 - c == 1) return; // a pair with a single chunk was written by k_schur_pairs itself
     for (; c + 3 < c1; c += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) s4[u] += slab[(size_t)(c + u) * BA_SLAB + e];

@@ -106,8 +106,11 @@ template <typename T> struct Solver final : SolverBase {
     int N = 0, D = 0, Dp = 0, ld = 0, Ml = 0, Kl = 0;
     T tau = (T)0.5; // INLIER_THRESHOLD, src/bundle_adjustment_large.cpp:36
     // structure
-    DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_ent_r, d_ent_c, d_chunk_ptr, d_pair_chunk_ptr,
+    DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_pair_chunk_ptr,
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
+    DevBuf<int4> d_chunk_info; // per chunk of the pair kernel: first entry, count | BA_CHUNK_SINGLE, camera hi, camera lo
+    DevBuf<int2> d_ent;        // per entry: row observation, column observation (~point for a self entry)
+    ba_bands bands{};          // chunk ranges of the 8 XCD bands
     // state and work arrays
     // linearisation (r, J, J^T r, block diagonals, MOREQR's outer factors): one set per parameter buffer, so that the
     // linearisation at xTest can be enqueued while the trial that produced xTest is still being judged on the host
@@ -139,7 +142,7 @@ template <typename T> struct Solver final : SolverBase {
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
     {
         kind = k; rank = rk; world = wd;
-        int rc = ba_build_structure(p, rk, wd, 32, &sx);
+        int rc = ba_build_structure(p, rk, wd, BA_CHUNK, 32 /* lanes of a k_cam_gram group */, &sx);
         if (rc) return rc;
         N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
         Dp = ((D + NAUG + NB - 1) / NB) * NB;
@@ -163,10 +166,30 @@ template <typename T> struct Solver final : SolverBase {
         }
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
-        UP(d_pair_lo, sx.pair_lo); UP(d_ent_r, sx.ent_r); UP(d_ent_c, sx.ent_c); UP(d_chunk_ptr, sx.chunk_ptr);
+        UP(d_pair_lo, sx.pair_lo);
         UP(d_pair_chunk_ptr, sx.pair_chunk_ptr); UP(d_dchunk_ptr, sx.dchunk_ptr); UP(d_cam_dchunk_ptr, sx.cam_dchunk_ptr);
         UP(d_cam_obs, sx.cam_obs); UP(d_qr_pts, sx.qr_pts);
 #undef UP
+        {
+            std::vector<int4> ci((size_t)sx.nchunks);
+            for (int c = 0; c < sx.nchunks; c++) {
+                const int q = sx.chunk_pair[c];
+                const bool single = sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] == 1;
+                ci[c] = make_int4(sx.chunk_ptr[c], (sx.chunk_ptr[c + 1] - sx.chunk_ptr[c]) | (single ? BA_CHUNK_SINGLE : 0), sx.pair_hi[q], sx.pair_lo[q]);
+            }
+            std::vector<int2> en((size_t)sx.E);
+            for (long long e = 0; e < sx.E; e++) { // a self entry carries ~point in place of its column observation (k_schur_pairs)
+                const int r_ = sx.ent_r[(size_t)e], c_ = sx.ent_c[(size_t)e];
+                en[(size_t)e] = make_int2(r_, r_ == c_ ? ~sx.obs_pt[r_] : c_);
+            }
+            if ((rc = d_chunk_info.upload(ci)) || (rc = d_ent.upload(en))) return rc;
+            // 8 bands of chunks with equal numbers of entries, one per XCD
+            for (int b = 0, c = 0; b <= BA_NBAND; b++) {
+                const long long target = sx.E * b / BA_NBAND;
+                while (c < sx.nchunks && sx.chunk_ptr[c] < target) c++;
+                bands.ptr[b] = b == BA_NBAND ? sx.nchunks : c;
+            }
+        }
         // parameters: bundle_adjustment_large.cpp:81-107 (K00 = -f, R = Rodrigues(omega), distortion (k1 f^2, k2 f^4))
         std::vector<T> cam((size_t)15 * N), pts((size_t)3 * (Ml > 0 ? Ml : 1)), meas((size_t)2 * (Kl > 0 ? Kl : 1));
         for (int i = 0; i < N; i++) {
@@ -361,9 +384,18 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_schur()
     {
-        if (sx.nchunks > 0)
-            hipLaunchKernelGGL((k_schur_chunks<T>), dim3((sx.nchunks * 32 + 255) / 256), dim3(256), 0, st, sx.nchunks,
-                               d_chunk_ptr.p, d_ent_r.p, d_ent_c.p, d_rec.p, d_slab.p);
+        if (sx.nchunks > 0) {
+            // persistent: 4 workgroups per CU, the workgroups of one XCD walk one band of the chunk list (see k_schur_pairs)
+            int wgb = 1; // workgroups per band
+            for (int b = 0; b < BA_NBAND; b++) wgb = std::max(wgb, (bands.ptr[b + 1] - bands.ptr[b] + 3) / 4);
+            const dim3 gp(BA_NBAND * std::min(wgb, std::max(1, 4 * num_cus / BA_NBAND)));
+            if (kind == BA_CHOLESKY) // the only symbol whose point blocks carry a diagonal D (dinv != 1)
+                hipLaunchKernelGGL((k_schur_pairs<T, true>), gp, dim3(256), 0, st, bands, d_chunk_info.p, d_ent.p, d_rec.p, d_tvec.p, Ml, d_slab.p,
+                                   d_V[cur].p, d_gc[cur].p, D, ld, d_S.p);
+            else
+                hipLaunchKernelGGL((k_schur_pairs<T, false>), gp, dim3(256), 0, st, bands, d_chunk_info.p, d_ent.p, d_rec.p, d_tvec.p, Ml, d_slab.p,
+                                   d_V[cur].p, d_gc[cur].p, D, ld, d_S.p);
+        }
         const long long nthr = (long long)sx.npairs * BA_SLAB;
         hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, sx.npairs, D, ld,
                            d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V[cur].p, d_gc[cur].p, d_S.p);

@@ -11,9 +11,9 @@
 #include <algorithm>
 #include <numeric>
 
-int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int chunk_len, ba_structure *s)
+int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int chunk_len, int dchunk_len, ba_structure *s)
 {
-    if (!p || !s || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || chunk_len < 1) return BA_ERR_ARG;
+    if (!p || !s || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || chunk_len < 1 || dchunk_len < 1) return BA_ERR_ARG;
     const int N = p->N, M = p->M, K = p->K;
     s->N = N; s->M = M; s->K = K; s->chunk_len = chunk_len;
 
@@ -126,7 +126,7 @@ int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int
     s->nchunks = (int)s->chunk_pair.size();
     s->chunk_ptr.push_back((int)s->E);
 
-    // 5. camera-sorted view of the observations (= self entries of the diagonal pairs), chunked the same way.
+    // 5. camera-sorted view of the observations (= self entries of the diagonal pairs), in chunks of dchunk_len.
     std::vector<int> cptr((size_t)N + 1, 0);
     for (int i = 0; i < Kl; i++) cptr[(size_t)s->obs_cam[i] + 1]++;
     for (int c = 0; c < N; c++) cptr[c + 1] += cptr[c];
@@ -139,7 +139,7 @@ int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int
     s->dchunk_ptr.clear();
     s->dchunk_cam.clear();
     for (int c = 0; c < N; c++) {
-        for (int b = cptr[c]; b < cptr[c + 1]; b += chunk_len) {
+        for (int b = cptr[c]; b < cptr[c + 1]; b += dchunk_len) {
             s->dchunk_ptr.push_back(b);
             s->dchunk_cam.push_back(c);
         }
@@ -154,7 +154,7 @@ extern "C" int ba_shard_plan(const ba_problem *p, int shard_rank, int shard_worl
 {
     if (!p || !out8) return BA_ERR_ARG;
     ba_structure s;
-    int rc = ba_build_structure(p, shard_rank, shard_world, 32, &s);
+    int rc = ba_build_structure(p, shard_rank, shard_world, 64, 32, &s);
     if (rc) return rc;
     out8[0] = s.p0; out8[1] = s.p1; out8[2] = s.o0; out8[3] = s.o1; out8[4] = s.E; out8[5] = s.nchunks; out8[6] = s.npairs;
     out8[7] = s.was_sorted ? 1 : 0;

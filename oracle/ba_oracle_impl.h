@@ -704,6 +704,10 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
                  const S *fvec, S lambda, S *dx, S *Sout, S *rhsout, S *gout, S *diagmax)
 {
     const int D = 9 * N;
+    /* kind | 256: assemble only (elimination + reduced system into Sout / rhsout), no factorisation, dx untouched --
+     * for parity checks of the assembly at sizes where the plain-C dense LDL^T would take minutes (D = 9216) */
+    const int assemble_only = (kind & 256) != 0;
+    kind &= 255;
     int *pt_ptr = (int *)malloc(sizeof(int) * ((size_t)M + 1));
     /* observations must be sorted by point (BAL files are; BacktrackLevMarqQRChol.h:291-309 relies on it) */
     {
@@ -748,14 +752,16 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     if (Sout) memcpy(Sout, Smat, sizeof(S) * (size_t)D * D);
     if (rhsout) memcpy(rhsout, rhs, sizeof(S) * (size_t)D);
     S *dxc = dx + 3 * (size_t)M;
-    if (kind == 0) {
+    if (assemble_only) {
+        /* nothing to solve */
+    } else if (kind == 0) {
         rc = FN(solve_reduced_qr)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, Q1obs, Q1lam, dxc);
     } else {
         FN(dense_ldlt)(D, Smat);
         FN(dense_ldlt_solve)(D, Smat, rhs);
         for (int c = 0; c < D; c++) dxc[c] = rhs[c];
     }
-    FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
+    if (!assemble_only) FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
     if (gout || diagmax) FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, gout, diagmax);
     free(Q1obs); free(Q1lam);
     free(e.Z); free(e.dinv); free(e.t); free(e.tri);
@@ -769,13 +775,14 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
  * BacktrackLevMarqCholesky::minimize (BacktrackLevMarqCholesky.h:190-361): same skeleton, different
  * inner solve.  QRKIT's loop (Eigen::BacktrackLevMarq) is not vendored; it reuses this skeleton.
  * lm = {lambda_min, lambda_max, increase_base, tol_fun}; max_iter / max_fun_ev as LMParams.
+ * snap (optional): the state x of every trial, for tests that inject it into another implementation.
  * trace: max_trials rows of 8 doubles {iter, accepted, f, rho, lambda_printed, lambda_used, e_test, |dx|}
  * (one row per printed table line, BacktrackLevMarqQRChol.h:383,397).  Stops early (status Running = -1)
  * after max_trials rows.  cam15/pts are updated in place with the reference's quirk that the flat-line
  * exit happens BEFORE x = xTest (:419-428).  Returns the Status integer (:39-46). */
 int FN(ora_minimize)(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *meas, S tau,
                      S *cam15, S *pts, const double *lm, int max_iter, int max_fun_ev, int max_trials, double *trace,
-                     int *ntrials_out)
+                     int *ntrials_out, double *snap /* NULL, or max_trials x (15N + 3M): the state x each trial starts from */)
 {
     const S lam_min = (S)lm[0], lam_max = (S)lm[1], inc_base = (S)lm[2], tol_fun = (S)lm[3];
     const size_t np = 3 * (size_t)M + 9 * (size_t)N;
@@ -806,6 +813,11 @@ int FN(ora_minimize)(int kind, int N, int M, int K, const int *cam_idx, const in
         }
         while (1) {
             if (ntr >= max_trials) { stop = 1; status = -1; break; }
+            if (snap) {
+                double *sn = snap + (size_t)ntr * (15 * (size_t)N + 3 * (size_t)M);
+                for (size_t c = 0; c < 15 * (size_t)N; c++) sn[c] = (double)cam15[c];
+                for (size_t c = 0; c < 3 * (size_t)M; c++) sn[15 * (size_t)N + c] = (double)pts[c];
+            }
             const int rc = FN(ora_step)(kind, N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, lambda, dx, NULL, NULL, NULL, NULL);
             if (rc) { status = -3; stop = 1; break; }
             FN(ora_retract)(N, M, cam15, pts, dx, camT, ptsT);

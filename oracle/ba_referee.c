@@ -1,0 +1,132 @@
+/*
+ * ba_referee.c -- TEST INFRASTRUCTURE ONLY: the CPU oracle instantiated a third time with S = __float128.
+ *
+ * Why: the reference ships no golden output and cannot be built here, so the fp64 oracle is
+ * "parity unpinned", and in the ill-conditioned part of an LM run (lambda at its 1e-10 floor, cond(J'J + lambda I)
+ * ~ 1e20) two correct fp64 solvers disagree about the step by O(1).  The referee decides who is closer to the truth:
+ * it evaluates ONE trial -- energy at x, step of (J'J + lambda I) dx = -J'r by the solver symbol's own elimination,
+ * retraction, test energy, rho denominator -- in 113-bit arithmetic from a state (x, lambda) given in double.  The
+ * fp64 oracle and the GPU are then both measured against it (tests/test_gpu_referee.py, tests/golden/referee_*.json).
+ *
+ * Same source as the oracle (ba_oracle_impl.h, with its reference file:line citations), so it inherits any misreading
+ * of the reference's FORMULAS; what it removes is rounding as an excuse.
+ *
+ * Build: make -C oracle   ->  oracle/libba_referee.so   (gcc, -lquadmath)
+ */
+#include <math.h>
+#include <quadmath.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+#define S __float128
+#define FN(name) CAT(name, _f128)
+#define SQRT sqrtq
+#define FABS fabsq
+#define SIN sinq
+#define COS cosq
+#define POW powq
+#include "ba_oracle_impl.h"
+
+/* One LM trial in quad precision from a double state.
+ *   kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY, 3 MOREQR (ba_oracle_impl.h: ora_step)
+ *   cam15 (15N), pts (3M), meas (2K), lambda: doubles, converted exactly
+ *   out[8] (rounded to double): 0 energy at x, 1 test energy at x (+) dx, 2 rho denominator dx'(lambda dx - J'r... see :375),
+ *                               3 |dx|, 4 max diag(J'J), 5 |J'r|, 6 backward error |(J'J + lambda I) dx + J'r| / |J'r|, 7 spare
+ *   dx_out (3M + 9N doubles, may be NULL): the quad step rounded to double
+ * Returns 0, or the oracle's error code. */
+int ref_trial(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau,
+              const double *cam15, const double *pts, double lambda, double *out, double *dx_out)
+{
+    const size_t np = 3 * (size_t)M + 9 * (size_t)N;
+    S *c = (S *)malloc(sizeof(S) * 15 * (size_t)N), *p = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    S *ms = (S *)malloc(sizeof(S) * 2 * (size_t)K), *f = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    S *Jc = (S *)malloc(sizeof(S) * 18 * (size_t)K), *Jp = (S *)malloc(sizeof(S) * 6 * (size_t)K);
+    S *dx = (S *)calloc(np, sizeof(S)), *g = (S *)malloc(sizeof(S) * np);
+    S *ct = (S *)malloc(sizeof(S) * 15 * (size_t)N), *pt = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    if (!c || !p || !ms || !f || !Jc || !Jp || !dx || !g || !ct || !pt) return -1;
+    for (size_t i = 0; i < 15 * (size_t)N; i++) c[i] = cam15[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) p[i] = pts[i];
+    for (size_t i = 0; i < 2 * (size_t)K; i++) ms[i] = meas[i];
+    const S e = ora_residuals_f128(N, M, K, c, p, cam_idx, pt_idx, ms, (S)tau, f);
+    ora_jacobian_f128(N, M, K, c, p, cam_idx, pt_idx, ms, (S)tau, Jc, Jp);
+    S dmax = 0;
+    int rc = ora_step_f128(kind, N, M, K, cam_idx, pt_idx, Jc, Jp, f, (S)lambda, dx, NULL, NULL, g, &dmax);
+    if (!rc) {
+        ora_retract_f128(N, M, c, p, dx, ct, pt);
+        const S et = ora_residuals_f128(N, M, K, ct, pt, cam_idx, pt_idx, ms, (S)tau, NULL);
+        S rs = 0, dn = 0, gn = 0;
+        for (size_t i = 0; i < np; i++) {
+            rs += dx[i] * ((S)lambda * dx[i] + g[i]); /* BacktrackLevMarqQRChol.h:375 (g = JtRes = -J'r) */
+            dn += dx[i] * dx[i];
+            gn += g[i] * g[i];
+        }
+        /* backward error in the normal equations, with the quad Jacobian */
+        S *res = (S *)calloc(np, sizeof(S));
+        for (int i = 0; i < K; i++) {
+            const S *A = Jc + 18 * (size_t)i, *B = Jp + 6 * (size_t)i;
+            const S *dc = dx + 3 * (size_t)M + 9 * (size_t)cam_idx[i], *dp = dx + 3 * (size_t)pt_idx[i];
+            S j0 = 0, j1 = 0;
+            for (int q = 0; q < 9; q++) { j0 += A[q] * dc[q]; j1 += A[9 + q] * dc[q]; }
+            for (int q = 0; q < 3; q++) { j0 += B[q] * dp[q]; j1 += B[3 + q] * dp[q]; }
+            S *rc_ = res + 3 * (size_t)M + 9 * (size_t)cam_idx[i], *rp = res + 3 * (size_t)pt_idx[i];
+            for (int q = 0; q < 9; q++) rc_[q] += A[q] * j0 + A[9 + q] * j1;
+            for (int q = 0; q < 3; q++) rp[q] += B[q] * j0 + B[3 + q] * j1;
+        }
+        S rn = 0;
+        for (size_t i = 0; i < np; i++) {
+            const S v = res[i] + (S)lambda * dx[i] - g[i];
+            rn += v * v;
+        }
+        free(res);
+        out[0] = (double)e; out[1] = (double)et; out[2] = (double)rs; out[3] = (double)sqrtq(dn); out[4] = (double)dmax;
+        out[5] = (double)sqrtq(gn); out[6] = (double)(sqrtq(rn) / sqrtq(gn)); out[7] = 0;
+        if (dx_out)
+            for (size_t i = 0; i < np; i++) dx_out[i] = (double)dx[i];
+    }
+    free(c); free(p); free(ms); free(f); free(Jc); free(Jp); free(dx); free(g); free(ct); free(pt);
+    return rc;
+}
+
+/* Elimination + reduced camera system of one trial in quad precision (no factorisation): S (D x D column-major, full
+ * symmetric) and the reduced rhs, rounded to double.  Decides whose S is closer to the truth where fp64 assemblies differ by
+ * more than the 1e-11 the small problems show (ill-conditioned 3x3 point blocks under a small lambda). */
+int ref_reduced(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau,
+                const double *cam15, const double *pts, double lambda, double *S_out, double *rhs_out)
+{
+    const size_t np = 3 * (size_t)M + 9 * (size_t)N, D = 9 * (size_t)N;
+    S *c = (S *)malloc(sizeof(S) * 15 * (size_t)N), *p = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    S *ms = (S *)malloc(sizeof(S) * 2 * (size_t)K), *f = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    S *Jc = (S *)malloc(sizeof(S) * 18 * (size_t)K), *Jp = (S *)malloc(sizeof(S) * 6 * (size_t)K);
+    S *dx = (S *)calloc(np, sizeof(S)), *Sq = (S *)malloc(sizeof(S) * D * D), *rq = (S *)malloc(sizeof(S) * D);
+    if (!c || !p || !ms || !f || !Jc || !Jp || !dx || !Sq || !rq) return -1;
+    for (size_t i = 0; i < 15 * (size_t)N; i++) c[i] = cam15[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) p[i] = pts[i];
+    for (size_t i = 0; i < 2 * (size_t)K; i++) ms[i] = meas[i];
+    (void)ora_residuals_f128(N, M, K, c, p, cam_idx, pt_idx, ms, (S)tau, f);
+    ora_jacobian_f128(N, M, K, c, p, cam_idx, pt_idx, ms, (S)tau, Jc, Jp);
+    const int rc = ora_step_f128(kind | 256, N, M, K, cam_idx, pt_idx, Jc, Jp, f, (S)lambda, dx, Sq, rq, NULL, NULL);
+    if (!rc) {
+        for (size_t i = 0; i < D * D; i++) S_out[i] = (double)Sq[i];
+        for (size_t i = 0; i < D; i++) rhs_out[i] = (double)rq[i];
+    }
+    free(c); free(p); free(ms); free(f); free(Jc); free(Jp); free(dx); free(Sq); free(rq);
+    return rc;
+}
+
+/* Energy only (quad) of a double state: what an fp64 evaluation of the test energy should have returned. */
+double ref_energy(int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau,
+                  const double *cam15, const double *pts)
+{
+    S *c = (S *)malloc(sizeof(S) * 15 * (size_t)N), *p = (S *)malloc(sizeof(S) * 3 * (size_t)M);
+    S *ms = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    for (size_t i = 0; i < 15 * (size_t)N; i++) c[i] = cam15[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) p[i] = pts[i];
+    for (size_t i = 0; i < 2 * (size_t)K; i++) ms[i] = meas[i];
+    const S e = ora_residuals_f128(N, M, K, c, p, cam_idx, pt_idx, ms, (S)tau, NULL);
+    free(c); free(p); free(ms);
+    return (double)e;
+}

@@ -1,0 +1,95 @@
+"""Generates tests/golden/referee_*.json: per-trial quad-precision (__float128) values along the fp64 oracle's LM trajectory.
+
+    python tests/golden/make_referee.py [case ...]        (about 10 minutes on 8 cores for all cases)
+
+For every trial k of the oracle's free run (to the reference's own stop, at most MAX_TRIALS rows) the state x_k the trial
+starts from and its lambda_k are handed, as doubles, to oracle/ba_referee.c, which evaluates the whole trial in 113-bit
+arithmetic: energy, step by the solver symbol's elimination, retraction, test energy, rho denominator.  The fixture keeps
+the oracle's own fp64 numbers beside the quad ones, so that (a) a test can check that its replay of the oracle is on the
+fixture's trajectory (energy column, bit-sensitive), and (b) the fp64 oracle's distance from the truth is on record for
+every lambda regime, including lambda < 1e-9 where cond(J'J + lambda I) > 1e19.
+
+The inputs are the two BAL files the reference ships (copied to data/) and one seeded synthetic problem; nothing of the
+reference's code is executed (it cannot be built here).
+"""
+import json
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import oracle_lib as O  # noqa: E402
+
+MAX_TRIALS = 260
+CASES = {
+    # name: (source, solver kind[, trials])
+    "problem21_qrchol": (("bal", "problem-21-11315-pre.txt"), O.QRCHOL),
+    "problem21_cholesky": (("bal", "problem-21-11315-pre.txt"), O.CHOLESKY),
+    "problem21_moreqr": (("bal", "problem-21-11315-pre.txt"), O.MOREQR),
+    "problem39_qrchol": (("bal", "problem-39-18060-pre.txt"), O.QRCHOL),
+    "synthetic60_cholesky": (("synthetic", (60, 3000, 14000, 2060)), O.CHOLESKY),
+    # the headline workload (config 4 stand-in): a quad trial costs ~5 CPU-minutes (dense LDL^T of 2313^2 in __float128),
+    # so only the first rows -- the ones the free-running prefix test of this config looks at
+    "cfg4_cholesky": (("synthetic", (257, 65132, 225911, 1004)), O.CHOLESKY, 8),
+    "cfg1_cholesky": (("synthetic", (16, 22106, 83718, 1001)), O.CHOLESKY, 24),
+}
+
+
+def load(source):
+    if source[0] == "bal":
+        return O.load_bal(os.path.join(ROOT, "data", source[1]))
+    import bundleadjustment_benchmarks_amd as ba  # host-side generator only (no GPU call)
+    a = ba.Problem.synthetic(*source[1])
+    arr = a.arrays()
+    return O.Problem(a.N, a.M, a.K, arr["cam_idx"], arr["pt_idx"], arr["meas"], arr["cams9"], arr["pts"])
+
+
+_P = {}
+
+
+def _one(args):
+    name, kind, k, state, lam = args
+    if name not in _P:
+        _P[name] = load(CASES[name][0])
+    p = _P[name]
+    q = O.referee_trial(kind, p, state[: 15 * p.N], state[15 * p.N:], lam)
+    return k, q
+
+
+def make(name, pool):
+    source, kind = CASES[name][:2]
+    max_trials = CASES[name][2] if len(CASES[name]) > 2 else MAX_TRIALS
+    p = load(source)
+    r = O.minimize(kind, p, max_trials=max_trials, snapshots=True)
+    tr, sn = r["trace"], r["snap"]
+    jobs = [(name, kind, k, sn[k], float(tr[k][5])) for k in range(len(tr))]
+    res = dict(pool.imap_unordered(_one, jobs, chunksize=1))
+    rows = []
+    for k in range(len(tr)):
+        q = res[k]
+        rows.append(dict(trial=k, iter=int(tr[k][0]), accepted=int(tr[k][1]), lam=float(tr[k][5]),
+                         energy_fp64=float(tr[k][2]), e_test_fp64=float(tr[k][6]), dx_norm_fp64=float(tr[k][7]),
+                         rho_fp64=float(tr[k][3]),
+                         energy_quad=q["energy"], e_test_quad=q["e_test"], rho_scale_quad=q["rho_scale"],
+                         dx_norm_quad=q["dx_norm"], backward_error_quad=q["backward_error"]))
+    out = dict(case=name, source=list(source[:1]) + [source[1] if isinstance(source[1], str) else list(source[1])], kind=int(kind),
+               N=p.N, M=p.M, K=p.K, status=int(r["status"]), max_trials=max_trials,
+               note="fp64 columns: oracle/ba_oracle.c free run; quad columns: oracle/ba_referee.c from the same (x, lambda) per trial",
+               trials=rows)
+    with open(os.path.join(HERE, "referee_%s.json" % name), "w") as f:
+        json.dump(out, f, indent=0)
+    e = np.array([[abs(w["e_test_fp64"] - w["e_test_quad"]) / w["e_test_quad"], w["lam"]] for w in rows])
+    print("%s: %d trials, status %d; fp64-vs-quad test-energy deviation: max %.2e (lambda %.1e), median %.2e" %
+          (name, len(rows), r["status"], e[:, 0].max(), e[e[:, 0].argmax(), 1], np.median(e[:, 0])), flush=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    with Pool(int(os.environ.get("REFEREE_PROCS", "8"))) as pool:
+        for n in names:
+            make(n, pool)

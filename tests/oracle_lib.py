@@ -17,8 +17,9 @@ LM_DEFAULTS = (1e-10, 1e10, 2.0, 1e-8)  # lambda min/max, increaseBase, tolFun (
 
 
 def build():
-    src = [os.path.join(_ROOT, "oracle", f) for f in ("ba_oracle.c", "ba_oracle_impl.h")]
-    if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src):
+    src = [os.path.join(_ROOT, "oracle", f) for f in ("ba_oracle.c", "ba_oracle_impl.h", "ba_referee.c", "Makefile")]
+    sos = [_SO, os.path.join(_ROOT, "oracle", "libba_referee.so")]
+    if all(os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in src) for so in sos):
         return _SO
     subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return _SO
@@ -133,6 +134,9 @@ def stats(p, cam15, pts, tau=0.5):
     return dict(mean_err=out[0], inlier_mean_err=out[1], n_inliers=int(out[2]), objective=out[3])
 
 
+ASSEMBLE_ONLY = 256  # or-ed into kind: elimination + reduced system only (no dense factorisation, dx = 0)
+
+
 def step(kind, p, Jc, Jp, fvec, lam, want_S=True):
     dt = fvec.dtype
     sfx, ct = _sfx(dt)
@@ -155,7 +159,8 @@ TRACE_COLS = ("iter", "accepted", "f", "rho", "lambda", "lambda_used", "e_test",
 
 
 def minimize(kind, p, dtype=np.float64, max_trials=1000000, lm=LM_DEFAULTS, max_iter=1000000, max_fun_ev=1000000, tau=0.5,
-             cam15=None, pts=None):
+             cam15=None, pts=None, snapshots=False):
+    """snapshots=True: also returns 'snap' (trials x (15N + 3M) doubles), the state x every trial started from."""
     sfx, ct = _sfx(dtype)
     cam15 = init_cams(p, dtype) if cam15 is None else cam15.copy()
     pts = p.pts.astype(dtype) if pts is None else pts.copy()
@@ -164,7 +169,63 @@ def minimize(kind, p, dtype=np.float64, max_trials=1000000, lm=LM_DEFAULTS, max_
     trace = np.zeros((cap, 8))
     lmv = np.asarray(lm, np.float64)
     ntr = C.c_int(0)
+    snap = np.zeros((cap, 15 * p.N + 3 * p.M)) if snapshots else None
     status = getattr(lib(), "ora_minimize" + sfx)(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(meas), ct(tau),
                                                   _p(cam15), _p(pts), _p(lmv), max_iter, max_fun_ev, cap, _p(trace),
-                                                  C.byref(ntr))
-    return dict(status=status, trace=trace[: ntr.value], cam15=cam15, pts=pts)
+                                                  C.byref(ntr), _p(snap))
+    out = dict(status=status, trace=trace[: ntr.value], cam15=cam15, pts=pts)
+    if snapshots:
+        out["snap"] = snap[: ntr.value]
+    return out
+
+
+_ref = None
+
+
+def referee():
+    """oracle/libba_referee.so: the same restatement in __float128 (ba_referee.c)."""
+    global _ref
+    if _ref is None:
+        build()
+        _ref = C.CDLL(os.path.join(_ROOT, "oracle", "libba_referee.so"))
+        _ref.ref_energy.restype = C.c_double
+    return _ref
+
+
+REF_COLS = ("energy", "e_test", "rho_scale", "dx_norm", "diagmax", "grad_norm", "backward_error", "spare")
+
+
+def referee_trial(kind, p, cam15, pts, lam, tau=0.5, want_dx=False):
+    """One LM trial in quad precision from the double state (cam15, pts, lam); see oracle/ba_referee.c."""
+    cam15 = np.ascontiguousarray(cam15, np.float64).reshape(-1)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1)
+    out = np.zeros(8)
+    dx = np.zeros(3 * p.M + 9 * p.N) if want_dx else None
+    rc = referee().ref_trial(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
+                             C.c_double(lam), _p(out), _p(dx))
+    if rc:
+        raise RuntimeError("ref_trial rc=%d" % rc)
+    r = dict(zip(REF_COLS, out))
+    if want_dx:
+        r["dx"] = dx
+    return r
+
+
+def referee_reduced(kind, p, cam15, pts, lam, tau=0.5):
+    """Reduced camera matrix (D x D, symmetric) and rhs of one trial assembled in quad precision, rounded to double."""
+    cam15 = np.ascontiguousarray(cam15, np.float64).reshape(-1)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1)
+    D = p.D
+    S = np.empty(D * D)
+    rhs = np.empty(D)
+    rc = referee().ref_reduced(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
+                               C.c_double(lam), _p(S), _p(rhs))
+    if rc:
+        raise RuntimeError("ref_reduced rc=%d" % rc)
+    return S.reshape(D, D).T, rhs
+
+
+def referee_energy(p, cam15, pts, tau=0.5):
+    cam15 = np.ascontiguousarray(cam15, np.float64).reshape(-1)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1)
+    return float(referee().ref_energy(p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts)))
