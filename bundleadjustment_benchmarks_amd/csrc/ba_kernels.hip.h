@@ -590,98 +590,117 @@ __global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__
 // observation == column observation, diagonal pairs; the entry list holds ~point in place of the column observation), so column
 // 9 of the tile is sum Z (dinv o t), the reduced-rhs term, for free.
 //
-// The kernel is a gather: 2 records (2 cache lines each) per entry, 65 MB of records at config 4, far beyond one XCD's 4 MiB L2.
-// What keeps most of those reads in L2 is the ORDER: the chunk list is sorted by (row camera, column camera); it is cut into 8
-// bands of equal work and the workgroups with equal blockIdx % 8 -- which the dispatcher places on one XCD (observed round-robin;
-// a speed assumption only) -- walk one band front to back, all 512 wavefronts of the XCD inside a window of 512 consecutive
-// chunks = a few row cameras.  The records a row camera needs (its own, and those of the other cameras of its points) are
-// largely the ones the previous row camera needed, so they are L2 hits; HBM / Infinity Cache sees each record about once.
+// The kernel is a gather of 2 records (256 B each in fp64) per entry, and what bounds it is neither bytes nor flops but
+// INSTRUCTION ISSUE (rocprofv3 counters of the first MFMA version: the SIMDs issued in 72 % of the kernel's cycles, 39 vector
+// instructions per MFMA -- 64-bit address arithmetic, masks, index shuffles -- while doubling the L2 hit rate or the occupancy
+// changed nothing).  So a lane owns one ENTRY of a group of four (k = entry, the three MFMAs of the group run over the point's
+// three coordinates): one index shuffle pair and one 32-bit offset per three MFMAs, raw-buffer loads with immediate offsets (no
+// 64-bit address arithmetic at all), and masking by out-of-range offsets (a raw buffer returns 0 there): lanes 9..15 of a row of
+// 16 and entries past the end of a chunk cost no select.  The loads of the next eight entries are in flight while the current
+// eight are multiplied.  (Also measured and dropped: staging whole records through LDS with 16-byte loads -- fewer, wider
+// requests, but a longer dependent chain per batch: 134 against 100 us.)
 //
-// One wavefront per chunk of <= 64 entries of one pair, persistent: a wavefront walks the chunks g, g + W, g + 2 W, ... of its
-// band and has the descriptor of the chunk after next and the entry indices of the next chunk in flight while it works on the
-// current one (one int4 per chunk: first entry, count | single-chunk flag, cameras hi and lo; one int2 per entry).  The entry
-// indices are handed round with ds_bpermute; the loads of eight entries (6 A + 6 dinv + 6 B per lane) are in flight while the
-// previous eight are multiplied.  A pair with a single chunk (almost all off-diagonal pairs) writes its block of S directly;
-// pairs with several chunks (diagonal pairs, heavy pairs) leave partial tiles in a slab that k_schur_reduce sums in chunk
-// order.  No atomics; the summation order is fixed by the static entry order, so the result is run-to-run reproducible.
+// One wavefront per chunk of <= 64 entries of one pair, persistent: the host deals the chunks to the wavefronts of the grid so that
+// every wavefront gets the same amount of work (longest-processing-time-first over the batch counts: chunk sizes run from 1 to 64
+// entries, and a plain stride gave the busiest wavefront twice the mean -- the kernel then ran 116 us with wavefronts alive 47 us on
+// average).  A wavefront walks its own list (wave_ptr) and has the descriptor of the chunk after next and the entry indices of the
+// next chunk in flight while it works on the current one (one int4 per chunk: first entry, count | single-chunk flag, cameras
+// hi | lo << 16, chunk id; one int2 per entry).  Optionally (nband = 8) the chunk list, which is sorted by (row camera, column
+// camera), is first cut into one range per XCD (workgroups with equal blockIdx % 8 share an XCD under the observed round-robin
+// placement), so that the records of neighbouring row cameras meet in one L2: L2 hits 46 % instead of 31 %.  A pair with a single chunk (almost all
+// off-diagonal pairs) writes its block of S directly; pairs with several chunks (diagonal pairs, heavy pairs) leave partial
+// tiles in a slab that k_schur_reduce sums in chunk order.  No atomics; the summation order is fixed by the static entry order,
+// so the result is run-to-run reproducible.
 #define BA_CHUNK_SINGLE (1 << 16) /* flag in chunk_info.y: the only chunk of its pair */
-#define BA_NBAND 8
-struct ba_bands { int ptr[BA_NBAND + 1]; }; // chunk range of each band
+typedef int ba_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ba_bufload(__amdgpu_buffer_rsrc_t r, unsigned off, const double *)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float ba_bufload(__amdgpu_buffer_rsrc_t r, unsigned off, const float *)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
 template <typename T, bool SCALED /* dinv != 1: CHOLESKY */>
-__global__ __launch_bounds__(256) void k_schur_pairs(ba_bands bands, const int4 *__restrict__ chunk_info, const int2 *__restrict__ ent,
-                                                     const T *__restrict__ rec, const T *__restrict__ tvec, int Ml, T *__restrict__ slab,
-                                                     const T *__restrict__ V, const T *__restrict__ gc, int D, int ld, T *__restrict__ S)
+__global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wave_ptr, int nband, const int4 *__restrict__ chunk_info,
+                                                     const int2 *__restrict__ ent, const T *__restrict__ rec, unsigned rec_bytes,
+                                                     const T *__restrict__ tvec, int Ml, T *__restrict__ slab, const T *__restrict__ V,
+                                                     const T *__restrict__ gc, int D, int ld, T *__restrict__ S)
 {
     const int lane = threadIdx.x & 63;
-    const int band = blockIdx.x % BA_NBAND;
-    const int W = (gridDim.x / BA_NBAND) * 4; // wavefronts per band (the grid is a multiple of BA_NBAND workgroups)
-    const int g1 = bands.ptr[band + 1];
-    int g = bands.ptr[band] + (blockIdx.x / BA_NBAND) * 4 + (threadIdx.x >> 6);
-    if (g >= g1) return; // (a whole wavefront leaves; the kernel has no workgroup barrier)
+    // wavefront index: the workgroups with equal blockIdx % nband (one XCD, observed) own one band of the chunk list
+    const int wq = ((blockIdx.x % nband) * (gridDim.x / nband) + blockIdx.x / nband) * 4 + (threadIdx.x >> 6);
+    int slot = wave_ptr[wq];
+    const int slot1 = wave_ptr[wq + 1];
+    if (slot >= slot1) return; // (a whole wavefront leaves; the kernel has no workgroup barrier)
+    // the records as a raw buffer: 32-bit byte offsets, immediate offsets in the instruction, 0 for every offset >= rec_bytes
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(rec), 0, (int)rec_bytes, 0x00020000);
+    constexpr unsigned SZ = sizeof(T), RB = BA_REC * SZ, OOB = 0xfffffff0u - 64 * SZ;
     const int i = lane & 15, k = lane >> 4;
-    // k-step 4 m + k of a group of four entries (m = 0, 1, 2) belongs to entry eo[m] of the group, coordinate kc[m]
-    const int eo0 = (k == 3) ? 1 : 0, eo1 = 1 + (k >= 2 ? 1 : 0), eo2 = 2 + (k >= 1 ? 1 : 0);
-    const int kc0 = (k == 3) ? 0 : k, kc1 = (k + 1) % 3, kc2 = (k + 2) % 3;
-    const bool la = i < 9, lb = i < 10;
-    const int offa = la ? 3 * i : 0; // element (i, .) of Z_a; lanes 9..15 of a row of 16 hold zeros
+    const bool la = i < 9;
+    const unsigned lane_off = 3 * i * SZ; // element (i, 0) of Z
     typedef typename ba_acc<T>::type acc_t;
     auto entry_of = [&](const int4 ci) { // this lane's entry of the chunk (lanes past the end shadow the last entry, their products are masked)
         const int n = ci.y & 0xffff;
         return ent[ci.x + (lane < n ? lane : n - 1)];
     };
-    int4 ci0 = chunk_info[g];
-    int4 ci1 = chunk_info[min(g + W, g1 - 1)];
+    int4 ci0 = chunk_info[slot];
+    int4 ci1 = chunk_info[min(slot + 1, slot1 - 1)];
     int2 en0 = entry_of(ci0);
-    for (; g < g1; g += W) {
+    for (; slot < slot1; slot++) {
         const int2 en1 = entry_of(ci1);                          // next chunk's indices: arrive under this chunk's work
-        const int4 ci2 = chunk_info[min(g + 2 * W, g1 - 1)];     // descriptor of the chunk after next
+        const int4 ci2 = chunk_info[min(slot + 2, slot1 - 1)];   // descriptor of the chunk after next
         const int n = ci0.y & 0xffff;
+        const int hi = ci0.z & 0xffff, lo = (unsigned)ci0.z >> 16, g = ci0.w;
+        const bool diag = hi == lo; // (uniform) only diagonal pairs have self entries, i.e. a reduced-rhs column
         const int ia_l = en0.x, ib_l = en0.y;
         acc_t acc;
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = 0;
         constexpr int GB = 2; // groups of four entries per batch
-        T av[3 * GB], dv[3 * GB], bv[3 * GB];
-        auto fetch = [&](int t0) { // operands of the entries 4 t0 .. 4 (t0 + GB) - 1
+        struct batch_t { T a[3 * GB], d[3 * GB], b[3 * GB]; };
+        auto fetch = [&](int t0, batch_t &o) { // operands of the entries 4 t0 .. 4 (t0 + GB) - 1: lane (i, k) takes entry k of each group
 #pragma unroll
             for (int u = 0; u < GB; u++) {
+                const int e = 4 * (t0 + u) + k;
+                const bool ok = e < n;
+                const int es = ok ? e : n - 1;
+                const int ia = __shfl(ia_l, es, 64), ibr = __shfl(ib_l, es, 64);
+                const bool self = ibr < 0; // self entry: the column observation is the row observation, ibr = ~point
+                const unsigned ra = (unsigned)ia * RB, rb = (unsigned)(self ? ia : ibr) * RB;
+                const unsigned oa = (ok && la) ? ra + lane_off : OOB, ob = (ok && la) ? rb + lane_off : OOB;
+                const unsigned od = (ok && la) ? ra + BA_REC_DINV * SZ : OOB;
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
-                    const int eo = m == 0 ? eo0 : m == 1 ? eo1 : eo2, kc = m == 0 ? kc0 : m == 1 ? kc1 : kc2;
-                    const int e = 4 * (t0 + u) + eo;
-                    const bool ok = e < n;
-                    const int es = ok ? e : n - 1;
-                    const int ia = __shfl(ia_l, es, 64), ibr = __shfl(ib_l, es, 64);
-                    const bool self = ibr < 0; // self entry: the column observation is the row observation, ibr = ~point
-                    const T *ra = rec + (size_t)ia * BA_REC;
-                    // B: column j = i of the tile: Z_b(j, kc) for j < 9; t(kc) of the point for j == 9 on a self entry
-                    const T *pb = (i < 9) ? rec + (size_t)(self ? ia : ibr) * BA_REC + 3 * i + kc
-                                          : (self ? tvec + (size_t)kc * Ml + (~ibr) : ra);
-                    const bool okb = ok && (i < 9 || (i == 9 && self));
-                    T a = 0, d = 1, b = 0;
-                    if (lb) { // (lanes 10..15 of every row of 16 issue no loads)
-                        a = ra[offa + kc];
-                        if (SCALED) d = ra[BA_REC_DINV + kc];
-                        b = *pb;
-                    }
-                    av[3 * u + m] = (ok && la) ? a : (T)0;
-                    dv[3 * u + m] = d;
-                    bv[3 * u + m] = okb ? b : (T)0;
+                    o.a[3 * u + m] = ba_bufload(rsrc, oa + m * SZ, (const T *)nullptr);
+                    if (SCALED) o.d[3 * u + m] = ba_bufload(rsrc, od + m * SZ, (const T *)nullptr);
+                    o.b[3 * u + m] = ba_bufload(rsrc, ob + m * SZ, (const T *)nullptr);
+                }
+                if (diag && i == 9 && ok && self) { // column 9 of B: t of the point (reduced rhs)
+#pragma unroll
+                    for (int m = 0; m < 3; m++) o.b[3 * u + m] = tvec[(size_t)m * Ml + (~ibr)];
                 }
             }
         };
+        auto multiply = [&](const batch_t &o) {
+#pragma unroll
+            for (int q = 0; q < 3 * GB; q++) acc = ba_mfma(SCALED ? o.a[q] * o.d[q] : o.a[q], o.b[q], acc);
+        };
+        // two register sets, ping-pong (no copies): the next batch is in flight under the MFMAs of the current one
         const int ngroups = (n + 3) >> 2;
-        fetch(0);
-        for (int t0 = 0; t0 < ngroups; t0 += GB) {
-            T ac[3 * GB], bc[3 * GB];
-#pragma unroll
-            for (int q = 0; q < 3 * GB; q++) { ac[q] = SCALED ? av[q] * dv[q] : av[q]; bc[q] = bv[q]; }
-            if (t0 + GB < ngroups) fetch(t0 + GB); // next batch in flight under the MFMAs of this one (uniform branch)
-#pragma unroll
-            for (int q = 0; q < 3 * GB; q++) acc = ba_mfma(ac[q], bc[q], acc);
+        batch_t b0, b1;
+        fetch(0, b0);
+        for (int t0 = 0;;) { // (uniform branches)
+            if (t0 + GB < ngroups) fetch(t0 + GB, b1);
+            multiply(b0);
+            t0 += GB;
+            if (t0 >= ngroups) break;
+            if (t0 + GB < ngroups) fetch(t0 + GB, b0);
+            multiply(b1);
+            t0 += GB;
+            if (t0 >= ngroups) break;
         }
         // tile element (row r, column j = i): r = ba_crow(k, v)
-        const int hi = ci0.z, lo = ci0.w;
         if (ci0.y & BA_CHUNK_SINGLE) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
@@ -689,9 +708,9 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ba_bands bands, const int4 
                 if (r >= 9) continue;
                 if (i < 9) {
                     T val = -acc[v];
-                    if (hi == lo) val += V[(size_t)hi * 81 + 9 * r + i];
+                    if (diag) val += V[(size_t)hi * 81 + 9 * r + i];
                     S[(size_t)(9 * lo + i) * ld + 9 * hi + r] = val;
-                } else if (i == 9 && hi == lo) {
+                } else if (i == 9 && diag) {
                     const T gg = gc[9 * hi + r];
                     S[(size_t)(9 * hi + r) * ld + D] = gg - acc[v];
                     S[(size_t)(9 * hi + r) * ld + D + 1] = gg;
@@ -716,20 +735,20 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ba_bands bands, const int4 
 // same all-reduce as S when the problem is sharded).  lambda I is added later by k_post_reduce (once, after the sum
 // over shards).
 template <typename T>
-__global__ __launch_bounds__(192) void k_schur_reduce(int npairs, int D, int ld, const int *__restrict__ pair_hi,
+__global__ __launch_bounds__(192) void k_schur_reduce(int nred, const int *__restrict__ red_pairs, int D, int ld, const int *__restrict__ pair_hi,
                                                       const int *__restrict__ pair_lo, const int *__restrict__ pair_chunk_ptr,
                                                       const T *__restrict__ slab, const T *__restrict__ V,
                                                       const T *__restrict__ gc, T *__restrict__ S)
 {
     const int idx = blockIdx.x * 192 + threadIdx.x;
-    const int p = idx / BA_SLAB, e = idx - p * BA_SLAB;
-    if (p >= npairs || e >= 90) return;
+    const int q = idx / BA_SLAB, e = idx - q * BA_SLAB;
+    if (q >= nred || e >= 90) return;
+    const int p = red_pairs[q]; // the pairs with no chunk or with several (k_schur_pairs writes the single-chunk ones itself)
     const int hi = pair_hi[p], lo = pair_lo[p];
     if (e >= 81 && hi != lo) return;
     T s4[4] = {0, 0, 0, 0}; // four interleaved partial sums (fixed order) keep four loads in flight
     const int c1 = pair_chunk_ptr[p + 1];
     int c = pair_chunk_ptr[p];
-    if (c1 - c == 1) return; // a pair with a single chunk was written by k_schur_pairs itself
     for (; c + 3 < c1; c += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) s4[u] += slab[(size_t)(c + u) * BA_SLAB + e];

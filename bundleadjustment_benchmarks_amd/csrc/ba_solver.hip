@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <numeric>
+#include <queue>
 #include <string>
 
 #define HIPCHK(x)                                                                                   \
@@ -110,7 +112,10 @@ template <typename T> struct Solver final : SolverBase {
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
     DevBuf<int4> d_chunk_info; // per chunk of the pair kernel: first entry, count | BA_CHUNK_SINGLE, camera hi, camera lo
     DevBuf<int2> d_ent;        // per entry: row observation, column observation (~point for a self entry)
-    ba_bands bands{};          // chunk ranges of the 8 XCD bands
+    DevBuf<int> d_wave_ptr;    // per wavefront of the pair kernel: its range of chunk descriptors
+    DevBuf<int> d_red_pairs;   // pairs k_schur_reduce writes: those without entries and those with several chunks
+    int nred = 0;
+    int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1;
     // state and work arrays
     // linearisation (r, J, J^T r, block diagonals, MOREQR's outer factors): one set per parameter buffer, so that the
     // linearisation at xTest can be enqueued while the trial that produced xTest is still being judged on the host
@@ -171,24 +176,76 @@ template <typename T> struct Solver final : SolverBase {
         UP(d_cam_obs, sx.cam_obs); UP(d_qr_pts, sx.qr_pts);
 #undef UP
         {
-            std::vector<int4> ci((size_t)sx.nchunks);
-            for (int c = 0; c < sx.nchunks; c++) {
-                const int q = sx.chunk_pair[c];
-                const bool single = sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] == 1;
-                ci[c] = make_int4(sx.chunk_ptr[c], (sx.chunk_ptr[c + 1] - sx.chunk_ptr[c]) | (single ? BA_CHUNK_SINGLE : 0), sx.pair_hi[q], sx.pair_lo[q]);
+            if (const char *ev = getenv("BA_SCHUR_WGS")) schur_wgs = std::max(1, std::min(8, atoi(ev)));
+            if (const char *ev = getenv("BA_SCHUR_BANDS")) schur_bands = atoi(ev);
+            // Chunks dealt to the wavefronts of the persistent pair kernel, longest first, always to the least loaded wavefront
+            // (cost = batches of eight entries + a constant per chunk); a wavefront's list is then walked in chunk order.
+            if (N > 65535) return BA_ERR_ARG; // (hi | lo << 16 in the chunk descriptor; a reduced matrix of that size would not fit anyway)
+            if ((unsigned long long)Kl * BA_REC * sizeof(T) >= 0xf0000000ull) return BA_ERR_ARG; // 32-bit record offsets: <= 15 M observations per shard (fp64)
+            {
+                // every wavefront of the persistent grid must be resident at once (the dealing assumes they run side by side)
+                int nb = 0;
+                const hipError_t oe = kind == BA_CHOLESKY ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, true>, 256, 0)
+                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, false>, 256, 0);
+                if (oe == hipSuccess && nb >= 1) schur_wgs = std::min(schur_wgs, nb);
             }
+            schur_grid = std::max(1, std::min((sx.nchunks + 3) / 4, schur_wgs * num_cus));
+            const int nband = (schur_bands > 1 && schur_grid >= 8 * schur_bands) ? schur_bands : 1;
+            schur_grid = schur_grid / nband * nband;
+            const int W = 4 * schur_grid, Wb = W / nband;
+            std::vector<int> order((size_t)sx.nchunks), owner((size_t)sx.nchunks), wptr((size_t)W + 1, 0);
+            auto cost = [&](int c) { return 2 * ((sx.chunk_ptr[c + 1] - sx.chunk_ptr[c] + 7) / 8) + 1; };
+            // bands: the chunk list (sorted by row camera, column camera) cut into nband ranges of equal cost; the workgroups with
+            // blockIdx % nband == b (one XCD under the observed round-robin placement) own range b.  Wavefront index: see k_schur_pairs.
+            std::vector<int> bptr((size_t)nband + 1, sx.nchunks);
+            {
+                long long tot = 0, acc = 0;
+                for (int c = 0; c < sx.nchunks; c++) tot += cost(c);
+                bptr[0] = 0;
+                for (int c = 0, b = 1; c < sx.nchunks && b < nband; c++) {
+                    acc += cost(c);
+                    while (b < nband && acc >= tot * b / nband) bptr[b++] = c + 1;
+                }
+            }
+            for (int b = 0; b < nband; b++) {
+                order.assign(bptr[b + 1] - bptr[b], 0);
+                std::iota(order.begin(), order.end(), bptr[b]);
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+                typedef std::pair<long long, int> load_t; // (load, wavefront): min-heap
+                std::priority_queue<load_t, std::vector<load_t>, std::greater<load_t>> heap;
+                for (int w = 0; w < Wb; w++) heap.push(load_t(0, b * Wb + w));
+                for (int c : order) {
+                    load_t t = heap.top();
+                    heap.pop();
+                    owner[c] = t.second;
+                    wptr[t.second + 1]++;
+                    heap.push(load_t(t.first + cost(c), t.second));
+                }
+            }
+            schur_nband = nband;
+            for (int w = 0; w < W; w++) wptr[w + 1] += wptr[w];
+            std::vector<int4> ci((size_t)sx.nchunks);
+            {
+                std::vector<int> cur(wptr.begin(), wptr.end() - 1);
+                for (int c = 0; c < sx.nchunks; c++) { // increasing chunk id inside every wavefront's list
+                    const int q = sx.chunk_pair[c];
+                    const bool single = sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] == 1;
+                    ci[cur[owner[c]]++] = make_int4(sx.chunk_ptr[c], (sx.chunk_ptr[c + 1] - sx.chunk_ptr[c]) | (single ? BA_CHUNK_SINGLE : 0),
+                                                    sx.pair_hi[q] | (sx.pair_lo[q] << 16), c);
+                }
+            }
+            if ((rc = d_wave_ptr.upload(wptr))) return rc;
+            std::vector<int> red;
+            for (int q = 0; q < sx.npairs; q++)
+                if (sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] != 1) red.push_back(q);
+            nred = (int)red.size();
+            if ((rc = d_red_pairs.upload(red))) return rc;
             std::vector<int2> en((size_t)sx.E);
             for (long long e = 0; e < sx.E; e++) { // a self entry carries ~point in place of its column observation (k_schur_pairs)
                 const int r_ = sx.ent_r[(size_t)e], c_ = sx.ent_c[(size_t)e];
                 en[(size_t)e] = make_int2(r_, r_ == c_ ? ~sx.obs_pt[r_] : c_);
             }
             if ((rc = d_chunk_info.upload(ci)) || (rc = d_ent.upload(en))) return rc;
-            // 8 bands of chunks with equal numbers of entries, one per XCD
-            for (int b = 0, c = 0; b <= BA_NBAND; b++) {
-                const long long target = sx.E * b / BA_NBAND;
-                while (c < sx.nchunks && sx.chunk_ptr[c] < target) c++;
-                bands.ptr[b] = b == BA_NBAND ? sx.nchunks : c;
-            }
         }
         // parameters: bundle_adjustment_large.cpp:81-107 (K00 = -f, R = Rodrigues(omega), distortion (k1 f^2, k2 f^4))
         std::vector<T> cam((size_t)15 * N), pts((size_t)3 * (Ml > 0 ? Ml : 1)), meas((size_t)2 * (Kl > 0 ? Kl : 1));
@@ -385,20 +442,18 @@ template <typename T> struct Solver final : SolverBase {
     void launch_schur()
     {
         if (sx.nchunks > 0) {
-            // persistent: 4 workgroups per CU, the workgroups of one XCD walk one band of the chunk list (see k_schur_pairs)
-            int wgb = 1; // workgroups per band
-            for (int b = 0; b < BA_NBAND; b++) wgb = std::max(wgb, (bands.ptr[b + 1] - bands.ptr[b] + 3) / 4);
-            const dim3 gp(BA_NBAND * std::min(wgb, std::max(1, 4 * num_cus / BA_NBAND)));
-            if (kind == BA_CHOLESKY) // the only symbol whose point blocks carry a diagonal D (dinv != 1)
-                hipLaunchKernelGGL((k_schur_pairs<T, true>), gp, dim3(256), 0, st, bands, d_chunk_info.p, d_ent.p, d_rec.p, d_tvec.p, Ml, d_slab.p,
-                                   d_V[cur].p, d_gc[cur].p, D, ld, d_S.p);
-            else
-                hipLaunchKernelGGL((k_schur_pairs<T, false>), gp, dim3(256), 0, st, bands, d_chunk_info.p, d_ent.p, d_rec.p, d_tvec.p, Ml, d_slab.p,
-                                   d_V[cur].p, d_gc[cur].p, D, ld, d_S.p);
+            // persistent: schur_wgs workgroups per CU, every wavefront walks its own balanced list of chunks (see k_schur_pairs)
+            const dim3 gp(schur_grid);
+#define BA_PAIRS(SC) hipLaunchKernelGGL((k_schur_pairs<T, SC>), gp, dim3(256), 0, st, d_wave_ptr.p, schur_nband, d_chunk_info.p, d_ent.p, d_rec.p, \
+                                        (unsigned)(sizeof(T) * d_rec.n), d_tvec.p, Ml, d_slab.p, d_V[cur].p, d_gc[cur].p, D, ld, d_S.p)
+            // SCALED: CHOLESKY is the only symbol whose point blocks carry a diagonal D (dinv != 1)
+            if (kind == BA_CHOLESKY) BA_PAIRS(true); else BA_PAIRS(false);
+#undef BA_PAIRS
         }
-        const long long nthr = (long long)sx.npairs * BA_SLAB;
-        hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, sx.npairs, D, ld,
-                           d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V[cur].p, d_gc[cur].p, d_S.p);
+        const long long nthr = (long long)nred * BA_SLAB;
+        if (nred > 0)
+            hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, nred, d_red_pairs.p, D, ld,
+                               d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V[cur].p, d_gc[cur].p, d_S.p);
     }
 
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
