@@ -9,10 +9,11 @@ next to the oracle's own error:
 
   * the oracle replay must be on the fixture's trajectory (its energies are bit-sensitive fingerprints of x_k);
   * the energy at x_k (no linear solve involved) agrees with quad to 1e-13;
-  * per trial |e_gpu - e_quad| <= max(4 |e_oracle - e_quad|, 4 x the largest oracle error among the trials of the same lambda decade):
-    the GPU is never an outlier of its regime -- no lambda is exempt (round 1 made no claim below lambda = 1e-9);
-  * per lambda decade the median GPU error is at most 3 x the median oracle error (+ 1e-13 + 1e-15 / lambda, a tenth of the error
-    level either side shows in that decade): as close to the truth as the oracle;
+  * per trial |e_gpu - e_quad| <= max(4 |e_oracle - e_quad|, 4 x the largest oracle error among the trials within one decade of
+    lambda either side) + 1e-13: the GPU is never an outlier of its regime -- no lambda is exempt (round 1 made no claim below
+    lambda = 1e-9);
+  * per lambda decade with at least four trials the median GPU error is at most 3 x the median oracle error, and over all trials
+    the geometric mean of (GPU error / oracle error) is at most 2: as close to the truth as the oracle (measured: 0.2 - 0.8);
   * where the quad step decides accept / reject by a margin beyond both fp64 errors, the GPU decides the same.
 """
 import json
@@ -80,12 +81,18 @@ def test_gpu_is_as_close_to_quad_as_the_oracle(ba, O, gpu_ok, name):
     print("\n%s: %d trials; per lambda decade: n, median / max error vs quad of the fp64 oracle and of the GPU" % (name, len(m)))
     for d, n, mo, mg, xo, xg in table:
         print("   1e%+03d  n=%3d  oracle %.2e / %.2e   gpu %.2e / %.2e" % (d, n, mo, xo, mg, xg))
-    for d, n, mo, mg, xo, xg in table:
-        sel = dec == d
-        floor = 1e-13 + 1e-15 / 10.0 ** d
-        bad = sel & (err_g > np.maximum(4 * err_o, 4 * xo) + floor)
-        assert not bad.any(), (name, "lambda decade 1e%d" % d, np.where(bad)[0][:5], err_g[bad][:5], err_o[bad][:5])
-        assert mg <= 3 * mo + floor, (name, "lambda decade 1e%d" % d, mg, mo)
+    ll = np.log10(lam)
+    for k in range(len(m)):  # never an outlier of its regime: the oracle errors within one decade of lambda either side set the cap
+        cap = 4 * err_o[np.abs(ll - ll[k]) <= 1.0].max()
+        assert err_g[k] <= max(4 * err_o[k], cap) + 1e-13, (name, k, lam[k], err_g[k], err_o[k], cap)
+    for d, n, mo, mg, xo, xg in table:  # as close to the truth as the oracle, wherever a decade holds enough trials for a median
+        if n >= 4:
+            assert mg <= 3 * mo + 1e-13, (name, "lambda decade 1e%d" % d, mg, mo)
+    ratio = np.maximum(err_g, 1e-15) / np.maximum(err_o, 1e-15)
+    gm = float(np.exp(np.mean(np.log(ratio))))
+    print("   geometric mean of (GPU error / oracle error) over all trials: %.2f; GPU closer to quad in %d of %d trials" %
+          (gm, int((err_g < err_o).sum()), len(m)))
+    assert gm <= 2.0, (name, gm)
     # accept / reject against the truth wherever the truth is decisive for both fp64 sides
     decisive = m[:, 8] > 10 * np.maximum(err_o, err_g) + 1e-12
     acc_g = m[:, 5] < m[:, 1]
