@@ -6,18 +6,19 @@
 
 A "step" is one Levenberg-Marquardt trial = one row of the reference's iteration table
 (src/Eigen_ext/BacktrackLevMarqCholesky.h:308,322): point elimination, Schur assembly, dense LDL^T + solve,
-back-substitution, retraction and the test-energy evaluation, plus (once per accepted trial) the residual /
+back-substitution, retraction, the test-energy evaluation and the step control, plus (once per accepted trial) the residual /
 Jacobian / gradient evaluation of the next outer iteration.  Workload (config.workload): BASELINE.json configs[3],
 the configuration the metric is quoted on -- CHOLESKY solver, problem-257-65132, fp64.  The BAL file is missing
 from the reference checkout (.MISSING_LARGE_BLOBS), so the seeded synthetic stand-in with the same
 (N, M, K) = (257, 65132, 225911) is used unless data/problem-257-65132-pre.txt exists.
 
 All inputs are resident in HBM before the timed region; the timed region is exactly K trials of ba_minimize().
-For N > 1 the points (and their observations) are sharded over the ranks and the reduced camera matrix is
-all-reduced over RCCL once per trial (strong scaling: the problem is fixed).
+For N > 1 the points (and their observations) are sharded over the ranks; the reduced camera system is all-reduced once per
+trial by RCCL INSIDE the library (ba_solver_comm_init), enqueued on the solver's stream without a host synchronisation (strong
+scaling: the problem is fixed).  torch.distributed (gloo) only carries the communicator id, the barriers and the max of the
+timings.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -34,8 +35,9 @@ WORKLOADS = {
     "cfg1": ("CHOLESKY", "f64", "problem-16-22106-pre.txt", (16, 22106, 83718), 1001),
     "cfg5": ("QRCHOL", "f64", None, (1024, 500000, 4000000), 1005),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_PEAK_TF = 78.6     # AMD's public MI355X fp64 matrix/vector figure (not in the local guide)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TF = 78.6     # AMD's public MI355X fp64 matrix/vector figure (not in the local guide; 64 cycles per v_mfma_f64_16x16x4, measured)
+FP32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 155 TF measured
 
 
 def load_problem(ba, name):
@@ -44,29 +46,6 @@ def load_problem(ba, name):
     if path and os.path.exists(path):
         return ba.Problem.load_bal(path), "file:data/" + fname
     return ba.Problem.synthetic(dims[0], dims[1], dims[2], seed), "synthetic(seed=%d)" % seed
-
-
-class DevArray:
-    """Zero-copy view of device memory for torch.as_tensor (__cuda_array_interface__)."""
-
-    def __init__(self, ptr, count, scalar):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8" if scalar == 0 else "<f4",
-                                         "data": (ptr, False), "version": 2, "strides": None}
-
-
-def make_allreduce(torch, dist, device):
-    cache = {}
-
-    def allreduce(ptr, count, scalar, op, stream):
-        key = (ptr, count, scalar)
-        t = cache.get(key)
-        if t is None:
-            t = torch.as_tensor(DevArray(ptr, count, scalar), device=device)
-            assert t.data_ptr() == ptr
-            cache[key] = t
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
-        return 0
-    return allreduce
 
 
 def algorithmic_bytes(N, M, K, S=8):
@@ -79,7 +58,8 @@ def algorithmic_bytes(N, M, K, S=8):
 
 
 def cpu_baseline(name, prob, budget_s=20.0):
-    """The CPU oracle (single thread, like the reference) timed on a bounded sample of the same workload."""
+    """The CPU oracle timed on a bounded sample of the same workload: ONE thread like the reference (no OpenMP / TBB in its build,
+    clock() timing), and -- labelled as not the reference -- the same port with OpenMP on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -91,17 +71,30 @@ def cpu_baseline(name, prob, budget_s=20.0):
     a = prob.arrays()
     po = O.Problem(prob.N, prob.M, prob.K, a["cam_idx"], a["pt_idx"], a["meas"], a["cams9"], a["pts"])
     dt = np.float64 if scalar == "f64" else np.float32
-    okind = {"QRKIT": O.QRCHOL, "QRCHOL": O.QRCHOL, "CHOLESKY": O.CHOLESKY}[kind]  # dense QRKIT right block is O(K D^2)
-    t0 = time.perf_counter()
-    O.minimize(okind, po, dtype=dt, max_trials=1)
-    t1 = time.perf_counter() - t0
-    n = max(2, min(50, int(budget_s / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    r = O.minimize(okind, po, dtype=dt, max_trials=n)
-    el = time.perf_counter() - t0
-    ntr = len(r["trace"])
-    return {"value": ntr / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-            "sample": "first %d LM trials of the same workload by oracle/ba_oracle.c (gcc -O2, 1 thread), %.1f s" % (ntr, el)}
+    # QRKIT: the oracle's dense thin QR of the right block is O(K D^2) -- timed through the QRCHOL loop it shares everything else with
+    okind = {"QRKIT": O.QRCHOL, "QRCHOL": O.QRCHOL, "CHOLESKY": O.CHOLESKY}[kind]
+
+    def timed(threads, budget):
+        O.set_threads(threads)
+        t0 = time.perf_counter()
+        O.minimize(okind, po, dtype=dt, max_trials=1)
+        t1 = time.perf_counter() - t0
+        n = max(2, min(50, int(budget / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        r = O.minimize(okind, po, dtype=dt, max_trials=n)
+        el = time.perf_counter() - t0
+        return len(r["trace"]), el
+
+    ntr, el = timed(1, budget_s)
+    out = {"value": ntr / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+           "sample": "first %d LM trials of the same workload by oracle/ba_oracle.c (gcc -O2, 1 thread, blocked dense LDL^T), %.1f s" % (ntr, el)}
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if ncores > 1:
+        ntr2, el2 = timed(ncores, budget_s / 2)
+        out["all_cores"] = {"value": ntr2 / el2, "cores": ncores, "note": "the same port with OpenMP on every host core -- NOT the reference "
+                            "(which is single-threaded); first %d trials, %.1f s" % (ntr2, el2)}
+        O.set_threads(1)
+    return out
 
 
 def main():
@@ -126,12 +119,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        dist.init_process_group(backend="gloo")  # control plane only: id exchange, barriers, max of the timings
 
     kind_s, scalar_s, _, _, _ = WORKLOADS[args.workload]
     kind = {"QRKIT": ba.QRKIT, "QRCHOL": ba.QRCHOL, "CHOLESKY": ba.CHOLESKY}[kind_s]
@@ -139,8 +131,9 @@ def main():
     prob, source = load_problem(ba, args.workload)
     solver = ba.Solver(prob, kind, scalar, device=local_rank, shard_rank=rank, shard_world=world)
     if world > 1:
-        solver.set_stream(torch.cuda.current_stream().cuda_stream)
-        solver.set_allreduce(make_allreduce(torch, dist, device))
+        ids = [ba.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        solver.comm_init(ids[0])  # ncclCommInitRank inside the library: the data path's all-reduces are its own
     cam0 = solver.get(ba.GET_CAMS)
     pts0 = solver.get(ba.GET_POINTS)
 
@@ -161,7 +154,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     steps_done = res["trials"]
@@ -174,21 +167,21 @@ def main():
         D = 9 * N
         b_evalRJ, b_evalR, b_schur = algorithmic_bytes(N, M, K, S)
         ntr = max(tm["n_trials"], 1)
-        phases = {k: tm[k] / ntr for k in ("eliminate_ms", "schur_ms", "factor_ms", "backsub_ms", "test_eval_ms", "trial_ms")}
-        phases["graph_replayed_trials"] = tm["n_graph_trials"]  # replayed trials only time the whole trial (trial_ms)
-        phases["linearize_ms"] = tm["linearize_ms"] / max(tm["n_linearize"], 1)
+        label = kind_s + (" symbol (runs the QRCHOL loop: per-point QR + LDL^T of the reduced system, DESIGN.md section 2)" if kind_s == "QRKIT" else " solver")
         out = {
             "metric": "LM iterations/sec", "value": steps_done / el, "unit": "LM iterations/s", "n_gpus": world,
             "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps_done, 1),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else None, "vs_baseline": None,
             "dtype": scalar_s, "data": "synthetic" if source.startswith("synthetic") else source,
-            "config": {"workload": "%s solver, BAL problem-%d-%d (K=%d) %s, %s" % (kind_s, N, M, K, source, scalar_s),
-                       "sharding": "points over %d rank(s), RCCL all-reduce of the %dx%d reduced camera matrix per trial" % (world, D, D)
+            "config": {"workload": "%s, BAL problem-%d-%d (K=%d) %s, %s" % (label, N, M, K, source, scalar_s),
+                       "sharding": "points over %d rank(s), RCCL all-reduce (inside the library) of the packed %dx%d reduced camera system per trial" % (world, D, D)
                        if world > 1 else "single GPU"},
             "schur_solve_ms": res["schur_ms"], "linearize_ms": res["linearize_ms"],
             "final_energy": res["energy"], "lm_status": ba.STATUS.get(res["status"], str(res["status"])),
-            "accepted_iterations": res["iterations"] - (0 if res["status"] != -1 else 1),
-            "phase_ms": phases, "comm_ms_per_trial": tm["comm_ms"] / ntr,
+            "accepted_iterations": res["iterations"] - 1,
+            "trial_device_ms": tm["trial_ms"] / ntr, "comm_ms_per_trial": tm["comm_ms"] / ntr,
+            # what the host adds per step on top of the device time of the trial and of the (conditional) linearisation behind it
+            "host_overhead_ms_per_step": 1e3 * el / max(steps_done, 1) - (tm["trial_ms"] + tm["linearize_ms"]) / ntr,
         }
     # roofline of the dominant kernel, measured live with HIP events on the solver's stream (rank 0, N=1 only)
     if world == 1:
@@ -205,26 +198,23 @@ def main():
         flops_factor = D ** 3 / 3.0
         by_hbm = b_schur - 3 * D * D * S
         t_hbm = ph["eliminate"] + ph["schur_assembly"] + ph["backsub_retract"]
-        secondary = {"bound": "hbm", "kernel": "k_elim_* + k_schur_chunks + k_schur_reduce + k_backsub", "achieved": by_hbm / (t_hbm * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm}
+        secondary = {"bound": "hbm", "kernel": "k_elim_* + k_schur_pairs + k_schur_reduce + k_backsub", "achieved": by_hbm / (t_hbm * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm,
+                     "traffic": None}
         if ph["dense_factor"] >= t_hbm:
             # k_ldlt_step (fused panel + trailing update; k_ldlt_panel for the first block column): nblk launches per trial,
             # each processing 1/nblk of the D^3/3 flops on average
+            peak = FP64_PEAK_TF if S == 8 else FP32_PEAK_TF
             ach = flops_factor / (ph["dense_factor"] * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(args.workload, {}).get("k_ldlt_step_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            # traffic: HBM bytes need PMC passes of their own (rocprofv3 --pmc cannot ride on this run): scripts/evidence.sh collects
+            # them with this same command and profiles/ holds the result; the line itself carries no stale number
             out["roofline"] = {"bound": "mfma", "kernel": "k_ldlt_step<%s,64> (fused panel + trailing update of the dense LDL^T of the %dx%d reduced camera matrix; k_ldlt_panel for the first block column)" % ("double" if S == 8 else "float", D, D),
-                               "achieved": ach, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TF, "traffic": traffic,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                                "launches_per_trial": nblk, "avg_launch_us": 1e3 * ph["dense_factor"] / nblk,
                                "algorithmic_flops_per_launch": flops_factor / nblk, "ms_per_trial": ph["dense_factor"],
                                "secondary": secondary}
         else:
-            out["roofline"] = dict(secondary, traffic=None)
+            out["roofline"] = secondary
         out["phase_replay_ms"] = ph
         out["algorithmic_bytes"] = {"evalRJ": b_evalRJ, "evalR": b_evalR, "schur": b_schur}
         if not args.no_cpu_baseline:

@@ -28,6 +28,7 @@ EXPORTS = [
     "ba_minimize", "ba_solver_linearize", "ba_solver_try_step", "ba_solver_accept", "ba_solver_stats", "ba_solver_get",
     "ba_solver_keep_intermediates", "ba_solver_set_state", "ba_solver_timing", "ba_solver_time_phase", "ba_device_info",
     "ba_version", "ba_shard_plan", "ba_problem_save_cache", "ba_problem_load_cache", "ba_solver_selftest",
+    "ba_comm_unique_id", "ba_comm_id_via_file", "ba_solver_comm_init",
 ]
 
 
@@ -103,6 +104,9 @@ def lib():
         L.ba_solver_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ba_solver_time_phase.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.ba_solver_selftest.argtypes = [C.c_void_p, C.c_int]
+        L.ba_comm_unique_id.argtypes = [C.c_void_p]
+        L.ba_comm_id_via_file.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.ba_solver_comm_init.argtypes = [C.c_void_p, C.c_void_p]
         L.ba_problem_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.ba_problem_get.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.ba_problem_load_bal.argtypes = [C.c_char_p, C.c_void_p]
@@ -293,6 +297,11 @@ class Solver:
     def set_stream(self, raw_stream):
         _chk(lib().ba_solver_set_stream(self._h, C.c_void_p(raw_stream)), "ba_solver_set_stream")
 
+    def comm_init(self, comm_id):
+        """RCCL inside the library: comm_id = the 128 bytes of comm_unique_id() from shard rank 0; collective over the shard group."""
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        _chk(lib().ba_solver_comm_init(self._h, buf), "ba_solver_comm_init")
+
     def set_allreduce(self, pyfunc):
         """pyfunc(dev_ptr:int, count:int, scalar:int, op:int, stream:int) -> int (0 = ok)."""
         def tramp(user, buf, count, scalar, op, stream):
@@ -304,6 +313,16 @@ class Solver:
                 return 1
         self._cb_keep = ALLREDUCE_FN(tramp)
         _chk(lib().ba_solver_set_allreduce(self._h, C.cast(self._cb_keep, C.c_void_p), None), "ba_solver_set_allreduce")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (call on shard rank 0, carry the bytes to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(lib().ba_comm_unique_id(buf), "ba_comm_unique_id")
+    return buf.raw
 
 
 def device_info(device=-1):

@@ -1,0 +1,134 @@
+// ba_comm.cpp -- RCCL inside the library: the one exchange step of the sharded LM trial (all-reduce of the packed reduced
+// camera system over xGMI) is issued by the C layer itself on the solver's stream, not by a host-language
+// callback.  The reference has no counterpart (single process, no communication); north_star asks for "a thin C-ABI host layer
+// ... with an RCCL all-reduce over xGMI on the reduced camera blocks".
+//
+// librccl.so.1 is opened on first use (dlopen), so that single-GPU users -- the executables, the tests -- neither load nor link
+// it; in a process that already holds an RCCL (PyTorch) the loader hands back that copy (same soname).
+#include "ba_internal.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+#include <thread>
+#include <unistd.h>
+
+namespace {
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+RcclApi &api()
+{
+    static RcclApi a;
+    if (a.h || a.ok) return a;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        a.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (a.h) break;
+    }
+    if (!a.h) {
+        fprintf(stderr, "ba_mi355x: cannot open librccl.so.1: %s\n", dlerror());
+        return a;
+    }
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.h, "ncclAllReduce");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+    if (!a.ok) fprintf(stderr, "ba_mi355x: librccl lacks an expected symbol\n");
+    return a;
+}
+
+int fail(const char *what, ncclResult_t r)
+{
+    fprintf(stderr, "ba_mi355x: %s failed: %s\n", what, api().GetErrorString ? api().GetErrorString(r) : "?");
+    return BA_ERR_COMM;
+}
+
+} // namespace
+
+static_assert(sizeof(ncclUniqueId) == BA_COMM_ID_BYTES, "BA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+int ba_rccl_init(void **comm_out, const void *id128, int rank, int world)
+{
+    RcclApi &a = api();
+    if (!a.ok) return BA_ERR_COMM;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = a.CommInitRank(&c, world, id, rank);
+    if (r != ncclSuccess) return fail("ncclCommInitRank", r);
+    *comm_out = (void *)c;
+    return BA_OK;
+}
+
+void ba_rccl_destroy(void *comm)
+{
+    if (comm && api().ok) (void)api().CommDestroy((ncclComm_t)comm);
+}
+
+// in place, on `stream`; f64: 1 = double, 0 = float; op 0 sum, 1 max
+int ba_rccl_allreduce(void *comm, void *buf, size_t count, int f64, int op, void *stream)
+{
+    RcclApi &a = api();
+    if (!a.ok || !comm) return BA_ERR_COMM;
+    const ncclResult_t r = a.AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, op == 0 ? ncclSum : ncclMax, (ncclComm_t)comm, (hipStream_t)stream);
+    return r == ncclSuccess ? BA_OK : fail("ncclAllReduce", r);
+}
+
+extern "C" {
+
+int ba_comm_unique_id(void *id_out)
+{
+    if (!id_out) return BA_ERR_ARG;
+    RcclApi &a = api();
+    if (!a.ok) return BA_ERR_COMM;
+    ncclUniqueId id;
+    const ncclResult_t r = a.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail("ncclGetUniqueId", r);
+    memcpy(id_out, &id, sizeof id);
+    return BA_OK;
+}
+
+// Rendezvous through a file for processes started by hand (the executables with BA_WORLD / BA_RANK): rank 0 creates the id and
+// publishes it with an atomic rename, the others wait for the file (60 s).
+int ba_comm_id_via_file(const char *path, int rank, void *id_out)
+{
+    if (!path || !id_out || rank < 0) return BA_ERR_ARG;
+    if (rank == 0) {
+        int rc = ba_comm_unique_id(id_out);
+        if (rc) return rc;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return BA_ERR_FILE;
+        const bool ok = fwrite(id_out, 1, BA_COMM_ID_BYTES, f) == BA_COMM_ID_BYTES;
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), path) != 0) return BA_ERR_FILE;
+        return BA_OK;
+    }
+    for (int tries = 0; tries < 600; tries++) {
+        FILE *f = fopen(path, "rb");
+        if (f) {
+            const size_t got = fread(id_out, 1, BA_COMM_ID_BYTES, f);
+            fclose(f);
+            if (got == BA_COMM_ID_BYTES) return BA_OK;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    return BA_ERR_COMM;
+}
+
+} // extern "C"

@@ -59,4 +59,9 @@ struct ba_structure {
 // chunk_len: entries per chunk of a camera pair (one wavefront of k_schur_pairs); dchunk_len: observations per chunk of a camera (k_cam_gram)
 int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int chunk_len, int dchunk_len, ba_structure *out);
 
+// RCCL transport (ba_comm.cpp); comm is an ncclComm_t
+int ba_rccl_init(void **comm_out, const void *id128, int rank, int world);
+void ba_rccl_destroy(void *comm);
+int ba_rccl_allreduce(void *comm, void *buf, size_t count, int f64, int op, void *stream);
+
 #endif

@@ -71,9 +71,10 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                                               const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
                                               T *__restrict__ Jp, T *__restrict__ JcA /* [K][20] AoS copy: A (18), r (2) */,
-                                              T *__restrict__ partial)
+                                              T *__restrict__ partial, const int *__restrict__ go = nullptr)
 {
     __shared__ T red[4];
+    if (go && *go == 0) return; // device-side LM control: the trial in front of this linearisation was rejected (uniform)
     const int i = blockIdx.x * 256 + threadIdx.x;
     T e2 = 0;
     if (i < K) {
@@ -202,9 +203,10 @@ __global__ __launch_bounds__(256) void k_stats(int K, int N, int Ml, const T *__
 struct ba_red_job { const void *src; int n; int op; int dst; }; // op 0 sum, 1 max
 struct ba_red_jobs { ba_red_job j[8]; };
 
-template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal)
+template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal, const int *__restrict__ go = nullptr)
 {
     __shared__ T red[4];
+    if (go && *go == 0) return;
     const ba_red_job jb = jobs.j[blockIdx.x];
     const T *src = (const T *)jb.src;
     T a = 0;
@@ -223,9 +225,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba
 template <typename T>
 __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
                                                     const T *__restrict__ r, T *__restrict__ U0, T *__restrict__ gp,
-                                                    T *__restrict__ partial_dmax)
+                                                    T *__restrict__ partial_dmax, const int *__restrict__ go = nullptr)
 {
     __shared__ T red[4];
+    if (go && *go == 0) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     T dm = 0;
     if (j < Ml) {
@@ -264,9 +267,10 @@ __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__
 template <typename T>
 __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
                                                   const int *__restrict__ cam_obs, const T *__restrict__ JcA,
-                                                  T *__restrict__ dslab)
+                                                  T *__restrict__ dslab, const int *__restrict__ go = nullptr)
 {
     __shared__ T xch[8][27][33];
+    if (go && *go == 0) return;
     const int gl = threadIdx.x >> 5, g = blockIdx.x * 8 + gl, sub = threadIdx.x & 31;
     const bool gok = g < ndchunks;
     const int e0 = gok ? dchunk_ptr[g] : 0, len = gok ? dchunk_ptr[g + 1] - e0 : 0;
@@ -305,8 +309,9 @@ __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int
 template <typename T>
 __global__ __launch_bounds__(192) void k_cam_gram_reduce(int N, const int *__restrict__ cam_dchunk_ptr,
                                                          const T *__restrict__ dslab, T *__restrict__ V /* [N][81] */,
-                                                         T *__restrict__ gc /* [9N] */)
+                                                         T *__restrict__ gc /* [9N] */, const int *__restrict__ go = nullptr)
 {
+    if (go && *go == 0) return;
     const int idx = blockIdx.x * 192 + threadIdx.x;
     const int a = idx / BA_SLAB, e = idx - a * BA_SLAB;
     if (a >= N || e >= 54) return;
@@ -407,8 +412,9 @@ template <typename T, int LPP, int SL> // SL observations per lane: points with 
 __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict__ pt_list, int Ml, int K, const int *__restrict__ pt_ptr,
                                                  const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ r,
                                                  const T *__restrict__ lam, T *__restrict__ rec, T *__restrict__ dinv,
-                                                 T *__restrict__ tvec, T *__restrict__ tri)
+                                                 T *__restrict__ tvec, T *__restrict__ tri, const int *__restrict__ go = nullptr)
 {
+    if (go && *go == 0) return; // (MOREQR's outer factorisation is part of the conditional linearisation)
     // the points of one track-length bucket (pt_list; the host buckets them so that a short track does not occupy the lanes
     // of the longest one)
     const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
@@ -794,9 +800,17 @@ __global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, cons
 // ---- multi-GPU: pack / unpack the block-lower trapezoid of S around the all-reduce ----------------------------------
 // Only rows >= 64 (c / 64) of column c carry data (lower triangle + the augmented rows D, D+1 at the bottom); packing
 // them into one contiguous buffer halves the bytes every rank sends over xGMI.  off[p] = start of block column p.
+// The packed buffer ends with one scalar: this shard's part of the energy of the latest linearisation (scal[eloc]) on the way
+// out, the energy summed over the shards (scal[etot]) on the way back -- the energy of an accepted step rides on the next
+// trial's all-reduce instead of costing a collective of its own.
 template <typename T, bool UNPACK>
-__global__ __launch_bounds__(256) void k_pack_lower(int Dp, int ld, T *__restrict__ S, T *__restrict__ buf)
+__global__ __launch_bounds__(256) void k_pack_lower(int Dp, int ld, T *__restrict__ S, T *__restrict__ buf, size_t ntail, T *__restrict__ scal,
+                                                    int eloc, int etot)
 {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (UNPACK) scal[etot] = buf[ntail];
+        else buf[ntail] = scal[eloc];
+    }
     const int c = blockIdx.y;                 // column
     const int p = c >> 6, r0 = p << 6;        // block column, first kept row
     const int h = Dp - r0;                    // kept rows of this column
@@ -915,6 +929,109 @@ __global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict
     rho = block_reduce<T, false>(rho, red);
     dn = block_reduce<T, false>(dn, red);
     if (threadIdx.x == 0) { scal[dst] = rho; scal[dst + 1] = dn; }
+}
+
+// ---- a-8: step control on the device ---------------------------------------------------------------------------
+// The accept / rho / lambda / flat-line logic of BacktrackLevMarqQRChol.h:374-428 (== BacktrackLevMarqCholesky.h:299-353) as a
+// one-lane kernel behind every trial, so that a whole LM run -- rejected retries included -- is enqueued without the host ever
+// waiting for a scalar: the trial kernels read lambda from scal[], k_commit (x = xTest, :428) and the linearisation kernels of
+// the next outer iteration look at lm->go.  Every trial leaves one row of the reference's table (:84-93) in a ring in pinned
+// host memory and then bumps `done` (system-scope release): the host prints / forwards rows as they appear and throttles its
+// enqueueing on `done`, nothing else.
+#define BA_LM_RING 64
+#define BA_DEV_FAILED (-100) /* status: a kernel raised the device error word (scal[err_slot]) */
+template <typename T> struct ba_lm_dev {
+    T lambda, lambda_inc, energy, hist0, hist1;
+    T lam_min, lam_max, tol_fun, inc_base;
+    int iter, trials, fun_evals, status, stop;
+    int go;       // the last trial was accepted and x = xTest is to happen: k_commit and the linearisation behind it run
+    int fresh;    // the linearisation at x has been redone since `energy` was set: take it from scal[SC energy slot]
+    int max_iter, max_fun_ev, max_trials, deverr;
+};
+struct ba_lm_row { double iter, accepted, f, rho, lambda, lambda_used, e_test, dx_norm; };
+struct ba_lm_host { int done, stop, status, pad; ba_lm_row rows[BA_LM_RING]; };
+struct ba_lm_slots { int energy, etest, rho_p, rho_c, dn_p, dn_c, lambda, err; }; // indices into scal[]
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_dev<T> *__restrict__ lm, ba_lm_host *__restrict__ host, ba_lm_slots sl)
+{
+    if (threadIdx.x != 0) return;
+    ba_lm_dev<T> s = *lm;
+    if (s.stop) { // a trial enqueued behind the end of the run: it changes nothing
+        if (s.go) lm->go = 0;
+        return;
+    }
+    if (s.fresh) { // m_functor(x, r) at the top of the outer iteration (:257): the accepted point re-evaluated
+        s.energy = scal[sl.energy];
+        s.fresh = 0;
+        s.fun_evals++;
+    }
+    const T e_test = scal[sl.etest];
+    const T rs = scal[sl.rho_p] + scal[sl.rho_c];
+    const T dn = scal[sl.dn_p] + scal[sl.dn_c];
+    s.fun_evals++;
+    const int t = s.trials++;
+    const T lam_used = s.lambda;
+    ba_lm_row row;
+    row.iter = s.iter; row.f = (double)s.energy; row.lambda_used = (double)lam_used; row.e_test = (double)e_test; row.dx_norm = sqrt((double)dn);
+    int go = 0;
+    if (scal[sl.err] != (T)0) { // a hand-off wait ran out inside this trial (ba_dense.hip.h): the step is garbage, stop loudly
+        s.deverr = (int)scal[sl.err];
+        scal[sl.err] = 0;
+        s.status = BA_DEV_FAILED;
+        s.stop = 1;
+        row.accepted = 0; row.rho = 0; row.lambda = (double)s.lambda;
+    } else if (e_test < s.energy) { // :374-394
+        const T rho = (s.energy - e_test) / rs;
+        const T tmv = (T)2.0 * rho - (T)1.0;
+        const T mul = (T)1.0 - tmv * tmv * tmv;
+        const T third = (T)1.0 / (T)3.0;
+        s.lambda *= (mul > third ? mul : third);
+        s.lambda = s.lambda > s.lam_min ? s.lambda : s.lam_min;
+        row.accepted = 1; row.rho = (double)rho; row.lambda = (double)s.lambda;
+        s.lambda_inc = s.inc_base;
+        s.energy = e_test;
+        if (s.iter % 2) s.hist1 = s.energy; else s.hist0 = s.energy;
+        const T maxf = s.hist0 > s.hist1 ? s.hist0 : s.hist1;
+        const T diff = s.energy > maxf ? s.energy - maxf : maxf - s.energy;
+        if (s.iter > 2 && diff < s.tol_fun * s.energy) { // flat-line: Success, and the loop leaves BEFORE x = xTest (:419-428)
+            s.status = 0;
+            s.stop = 1;
+        } else {
+            go = 1; // x = xTest, then the top of the next outer iteration (:243-254)
+            s.iter++;
+            s.fresh = 1;
+            if (s.iter > s.max_iter) { s.status = 3; s.stop = 1; }
+            else if (s.fun_evals > s.max_fun_ev) { s.status = 2; s.stop = 1; }
+        }
+    } else { // :395-410
+        row.accepted = 0; row.rho = 0; row.lambda = (double)s.lambda;
+        if (s.lambda > s.lam_max) { s.status = 1; s.stop = 1; }
+        else {
+            s.lambda *= s.lambda_inc;
+            s.lambda_inc = sizeof(T) == 8 ? (T)pow((double)s.lambda_inc, 1.5) : (T)powf((float)s.lambda_inc, 1.5f);
+        }
+    }
+    if (!s.stop && s.max_trials > 0 && s.trials >= s.max_trials) { s.stop = 1; s.status = -1; } // the max_trials extension: Running
+    s.go = go;
+    scal[sl.lambda] = s.lambda;
+    *lm = s;
+    host->rows[t % BA_LM_RING] = row;
+    host->stop = s.stop;
+    host->status = s.status;
+    __threadfence_system();
+    __hip_atomic_store(&host->done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// x = xTest (BacktrackLevMarqQRChol.h:428), when the control kernel said so (go == nullptr: unconditionally, ba_solver_accept).
+template <typename T>
+__global__ __launch_bounds__(256) void k_commit(int ncam, int npts, const T *__restrict__ cam_test, const T *__restrict__ pts_test,
+                                                T *__restrict__ cam, T *__restrict__ pts, const int *__restrict__ go)
+{
+    if (go && *go == 0) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < ncam) cam[idx] = cam_test[idx];
+    else if (idx - ncam < npts) pts[idx - ncam] = pts_test[idx - ncam];
 }
 
 #endif

@@ -29,7 +29,7 @@ const char *ba_error_string(int err)
     case BA_ERR_ARG: return "invalid argument";
     case BA_ERR_HIP: return "HIP runtime error / no MI355X device";
     case BA_ERR_NOMEM: return "out of memory";
-    case BA_ERR_COMM: return "all-reduce callback failed";
+    case BA_ERR_COMM: return "communication (RCCL / all-reduce callback) failed";
     }
     return "unknown error";
 }

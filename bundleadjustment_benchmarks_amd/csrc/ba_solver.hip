@@ -37,8 +37,11 @@ constexpr int NSCAL = 16;    // device scalar slots
 enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
        SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
        SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */,
-       SC_ERR = 14 /* device error word: a BA_DEVERR_* code written by a kernel whose in-launch hand-off wait ran out */ };
-enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_L0B, EV_L1B /* linearisation, one pair per buffer */, EV_F, EV_N };
+       SC_ERR = 14 /* device error word: a BA_DEVERR_* code written by a kernel whose in-launch hand-off wait ran out */,
+       SC_ELOC = 15 /* sharded: this shard's part of the energy of the latest linearisation (rides on the next packed all-reduce) */ };
+enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_N };
+constexpr int RING_EV = 8; // event slots of the trials in flight under ba_minimize (LM_DEPTH + the ones not yet harvested)
+constexpr int RING_NE = 6; // per slot: trial start | before / after the matrix all-reduce | before / after the scalar all-reduce | after control + linearisation
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -76,6 +79,7 @@ struct SolverBase {
     virtual int selftest(int which) = 0;
     ba_allreduce_fn ar_fn = nullptr;
     void *ar_user = nullptr;
+    void *comm = nullptr; // ncclComm_t of the shard group (ba_solver_comm_init)
     hipStream_t st = nullptr;
     bool own_stream = false;
     bool keep = false; // keep a copy of S / rhs before the factorisation (parity tests)
@@ -110,25 +114,28 @@ template <typename T> struct Solver final : SolverBase {
     // structure
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_pair_chunk_ptr,
         d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
-    DevBuf<int4> d_chunk_info; // per chunk of the pair kernel: first entry, count | BA_CHUNK_SINGLE, camera hi, camera lo
+    DevBuf<int4> d_chunk_info; // per chunk of the pair kernel: first entry, count | BA_CHUNK_SINGLE, cameras hi | lo << 16, chunk id
     DevBuf<int2> d_ent;        // per entry: row observation, column observation (~point for a self entry)
     DevBuf<int> d_wave_ptr;    // per wavefront of the pair kernel: its range of chunk descriptors
     DevBuf<int> d_red_pairs;   // pairs k_schur_reduce writes: those without entries and those with several chunks
     int nred = 0;
     int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1;
-    // state and work arrays
-    // linearisation (r, J, J^T r, block diagonals, MOREQR's outer factors): one set per parameter buffer, so that the
-    // linearisation at xTest can be enqueued while the trial that produced xTest is still being judged on the host
-    DevBuf<T> d_r[2], d_Jc[2], d_Jp[2], d_JcA[2], d_U0[2], d_gp[2], d_V[2], d_gc[2], d_rec0[2], d_dinv0[2], d_tvec0[2], d_tri0[2];
+    // state: x = d_cam[0], d_pts[0]; xTest = d_cam[1], d_pts[1] (x = xTest is a device-side copy, k_commit)
+    // linearisation at x (r, J, J^T r, block diagonals, MOREQR's outer factors): one set
+    DevBuf<T> d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_rec0, d_dinv0, d_tvec0, d_tri0;
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
-    int cur = 0; // index of x in d_cam / d_pts; 1 - cur is xTest
+    DevBuf<ba_lm_dev<T>> d_lm; // LM state of the device-side step control (k_lm_control)
+    ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
-    T *h_lam = nullptr;                      // pinned staging word for lambda
-    T *h_pin = nullptr;                      // pinned landing area of the device scalars (speculating trials)
-    hipGraphExec_t gexec[2] = {nullptr, nullptr}; // captured trial, one per parity of the parameter double buffer
+    T *h_lam = nullptr; // pinned staging word for lambda
+    // one LM trial as hipGraphs: world == 1: g_trial (elimination ... test energy), g_ctl (control, x = xTest, linearisation);
+    // sharded: g_a (elimination, assembly, pack) | all-reduce | g_b (unpack ... test energy) | all-reduce | g_ctl
+    hipGraphExec_t g_trial = nullptr, g_a = nullptr, g_b = nullptr, g_ctl = nullptr;
     bool use_graph = true;
     hipEvent_t ev[EV_N] = {};
+    struct EvSlot { hipEvent_t e[RING_NE]; };
+    EvSlot ring[RING_EV] = {};
     int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
     bool have_step = false;
     int num_cus = 256; // of the device the solver lives on
@@ -137,10 +144,14 @@ template <typename T> struct Solver final : SolverBase {
     {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
-        for (auto &g : gexec)
+        for (auto &sl : ring)
+            for (auto &e : sl.e)
+                if (e) (void)hipEventDestroy(e);
+        for (hipGraphExec_t g : {g_trial, g_a, g_b, g_ctl})
             if (g) (void)hipGraphExecDestroy(g);
         if (h_lam) (void)hipHostFree(h_lam);
-        if (h_pin) (void)hipHostFree(h_pin);
+        if (h_log) (void)hipHostFree((void *)h_log);
+        if (comm) ba_rccl_destroy(comm);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
 
@@ -160,8 +171,13 @@ template <typename T> struct Solver final : SolverBase {
         if (kind != BA_CHOLESKY && sx.kmax > 1024) return BA_ERR_ARG; // more than 1024 observations of one point: not supported by k_elim_qr
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        for (auto &sl : ring)
+            for (auto &e : sl.e) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipHostMalloc((void **)&h_lam, sizeof(T)));
-        HIPCHK(hipHostMalloc((void **)&h_pin, sizeof(T) * NSCAL));
+        // the LM table rows and the progress counter the control kernel writes: pinned, mapped, coherent host memory
+        HIPCHK(hipHostMalloc((void **)&h_log, sizeof(ba_lm_host), hipHostMallocMapped | hipHostMallocCoherent));
+        memset((void *)h_log, 0, sizeof(ba_lm_host));
+        HIPCHK(hipHostGetDevicePointer((void **)&d_log, (void *)h_log, 0));
         use_graph = getenv("BA_NO_GRAPH") == nullptr;
         {
             int dev = 0;
@@ -272,11 +288,10 @@ template <typename T> struct Solver final : SolverBase {
             return rc;
         const size_t K1 = Kl > 0 ? Kl : 1, M1 = Ml > 0 ? Ml : 1;
 #define AL(buf, n) if ((rc = buf.alloc(n))) return rc
-        for (int w = 0; w < 2; w++) {
-            AL(d_r[w], 2 * K1); AL(d_Jc[w], 18 * K1); AL(d_JcA[w], 20 * K1); AL(d_Jp[w], 6 * K1); AL(d_U0[w], 6 * M1); AL(d_gp[w], 3 * M1);
-            AL(d_V[w], (size_t)81 * N); AL(d_gc[w], (size_t)D);
-            if (kind == BA_MOREQR) { AL(d_rec0[w], (size_t)BA_REC * K1); AL(d_dinv0[w], 3 * M1); AL(d_tvec0[w], 3 * M1); AL(d_tri0[w], 6 * M1); }
-        }
+        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1);
+        AL(d_V, (size_t)81 * N); AL(d_gc, (size_t)D);
+        if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
+        if ((rc = d_lm.alloc(1))) return rc;
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
@@ -296,15 +311,16 @@ template <typename T> struct Solver final : SolverBase {
         return BA_OK;
     }
 
+    // Sum / max over the ranks that shard the problem, in place, ordered on the solver's stream: RCCL inside the library
+    // (ba_solver_comm_init) or the host layer's callback (ba_solver_set_allreduce; the gloo tests).
     int allreduce(void *buf, size_t count, int op)
     {
-        if (world <= 1) return BA_OK;
+        if (world <= 1 && !comm) return BA_OK;
+        if (comm) return ba_rccl_allreduce(comm, buf, count, sizeof(T) == 8, op, (void *)st);
         if (!ar_fn) return BA_ERR_COMM;
-        const auto t0 = std::chrono::steady_clock::now();
-        int rc = ar_fn(ar_user, buf, count, sizeof(T) == 8 ? BA_F64 : BA_F32, op, (void *)st);
-        tm.comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return rc ? BA_ERR_COMM : BA_OK;
+        return ar_fn(ar_user, buf, count, sizeof(T) == 8 ? BA_F64 : BA_F32, op, (void *)st) ? BA_ERR_COMM : BA_OK;
     }
+    bool sharded() const { return world > 1 || comm != nullptr; }
 
     int fetch_scalars()
     {
@@ -318,118 +334,117 @@ template <typename T> struct Solver final : SolverBase {
     int check_device_error()
     {
         if (h_scal[SC_ERR] == (T)0) return BA_OK;
-        fprintf(stderr, "ba_mi355x: device error %d: %s\n", (int)h_scal[SC_ERR],
-                (int)h_scal[SC_ERR] == BA_DEVERR_ROW_FLAG ? "k_ldlt_step: the look-ahead update of a row block was never announced"
-                                                          : "k_ldlt_backflow: an unknown of the backward sweep was never published");
+        report_device_error((int)h_scal[SC_ERR]);
         h_scal[SC_ERR] = 0;
         (void)hipMemsetAsync(d_scal.p + SC_ERR, 0, sizeof(T), st);
         return BA_ERR_HIP;
     }
-
-    double ev_ms(int a, int b)
+    static void report_device_error(int code)
     {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) return 0;
-        return ms;
+        fprintf(stderr, "ba_mi355x: device error %d: %s\n", code,
+                code == BA_DEVERR_ROW_FLAG ? "k_ldlt_step: the look-ahead update of a row block was never announced"
+                                           : "k_ldlt_backflow: an unknown of the backward sweep was never published");
     }
 
-    void launch_eval(bool jac, int which)
+    double ev_ms(hipEvent_t a, hipEvent_t b)
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0;
+        return ms;
+    }
+    double ev_ms(int a, int b) { return ev_ms(ev[a], ev[b]); }
+
+    // which: 0 = x, 1 = xTest
+    void launch_eval(bool jac, int which, const int *go = nullptr)
     {
         const T tau2 = tau * tau;
         if (jac)
             hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r[which].p, d_Jc[which].p, d_Jp[which].p, d_JcA[which].p, d_part_e.p);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go);
         else
             hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p, go);
     }
 
-    void launch_grad(int which)
+    void launch_grad(const int *go = nullptr)
     {
-        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp[which].p, d_r[which].p, d_U0[which].p, d_gp[which].p,
-                           d_part_pm.p);
+        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p, d_part_pm.p, go);
         if (sx.ndchunks > 0)
             hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
-                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA[which].p, d_dslab.p);
+                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
         hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
-                           d_dslab.p, d_V[which].p, d_gc[which].p);
+                           d_dslab.p, d_V.p, d_gc.p, go);
     }
 
-    // m_functor(x, r); energy; m_functor.df(x, J); JtRes; column norms (BacktrackLevMarqQRChol.h:257-280)
+    // m_functor(x, r); energy; m_functor.df(x, J); JtRes; column norms (BacktrackLevMarqQRChol.h:257-280), host-synchronous
     int linearize(double *energy, double *diag_max) override
     {
         int rc;
-        if ((rc = linearize_enqueue(diag_max != nullptr))) return rc;
-        if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
+        if ((rc = linearize_enqueue(diag_max != nullptr, nullptr))) return rc;
+        if (sharded()) { // the kernels left this shard's part in SC_ELOC (it also rides on the next trial's packed all-reduce)
+            HIPCHK(hipMemcpyAsync(d_scal.p + SC_ENERGY, d_scal.p + SC_ELOC, sizeof(T), hipMemcpyDeviceToDevice, st));
+            if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
+        }
         if (diag_max && (rc = allreduce(d_scal.p + SC_DMAX_P, 1, 1))) return rc;
         if ((rc = fetch_scalars())) return rc;
         HIPCHK(hipGetLastError());
-        linearize_account();
+        tm.linearize_ms += ev_ms(EV_L0, EV_L1);
+        tm.n_linearize++;
         if (energy) *energy = (double)h_scal[SC_ENERGY];
         if (diag_max) *diag_max = std::max((double)h_scal[SC_DMAX_P], (double)h_scal[SC_DMAX_C]);
         return BA_OK;
     }
 
-    // The launches of linearize() without the read-back: the energy lands in the device scalar slot SC_ENERGY, which the
-    // trial kernels do not touch, so a single-shard LM loop enqueues the trial right behind and reads both results with the
-    // one synchronisation of the trial (no host round trip between an accepted step and the next trial).
-    // which: the parameter buffer to linearise at -- cur, or 1 - cur = xTest of the trial just enqueued (speculation on its
-    // acceptance: the set of linearisation arrays of the other buffer is written, the current one stays intact for a retry).
-    int linearize_enqueue(bool want_dmax, int which = -1)
+    // The launches of the linearisation at x.  go != nullptr: conditional on the device-side step control (the kernels return
+    // at once unless the trial in front of them was accepted).  The energy lands in SC_ENERGY, or -- sharded -- this shard's part
+    // in SC_ELOC.
+    int linearize_enqueue(bool want_dmax, const int *go)
     {
         int rc;
-        const bool speculative = which >= 0 && which != cur;
-        if (which < 0) which = cur;
-        HIPCHK(hipEventRecord(ev[EV_L0 + 2 * which], st));
-        launch_eval(true, which);
-        launch_grad(which);
+        if (!go) HIPCHK(hipEventRecord(ev[EV_L0], st));
+        launch_eval(true, 0, go);
+        launch_grad(go);
         if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
-            launch_elim_qr(which, d_scal.p + SC_ZERO, d_rec0[which].p, d_dinv0[which].p, d_tvec0[which].p, d_tri0[which].p);
+            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go);
         ba_red_jobs jobs{};
         int nj = 0;
-        jobs.j[nj++] = {d_part_e.p, gK, 0, SC_ENERGY};
+        jobs.j[nj++] = {d_part_e.p, gK, 0, sharded() ? SC_ELOC : SC_ENERGY};
         if (want_dmax) {
             // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
             T *tmp = d_dxc.p;
-            hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V[which].p, tmp);
+            hipLaunchKernelGGL((k_vdiag<T>), dim3((D + 255) / 256), dim3(256), 0, st, N, d_V.p, tmp);
             if ((rc = allreduce(tmp, (size_t)D, 0))) return rc;
             jobs.j[nj++] = {d_part_pm.p, gM, 1, SC_DMAX_P};
             jobs.j[nj++] = {tmp, D, 1, SC_DMAX_C};
         }
-        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p);
-        HIPCHK(hipEventRecord(ev[EV_L1 + 2 * which], st));
-        if (!speculative) have_step = false;
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p, go);
+        if (!go) HIPCHK(hipEventRecord(ev[EV_L1], st));
+        have_step = false;
         return BA_OK;
-    }
-
-    void linearize_account() // of the linearisation at the current buffer (its events are complete: its results have been used)
-    {
-        tm.linearize_ms += ev_ms(EV_L0 + 2 * cur, EV_L1 + 2 * cur);
-        tm.n_linearize++;
     }
 
     void launch_eliminate()
     {
         if (kind == BA_CHOLESKY) {
-            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc[cur].p, d_Jp[cur].p,
-                               d_U0[cur].p, d_gp[cur].p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
+                               d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else if (kind == BA_MOREQR) {
             if (Kl > 0) // BacktrackLevMarqMore.h:297-345, the per-trial QR of [R ; sqrt(lambda) I]
                 hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
-                                   d_rec0[cur].p, d_tri0[cur].p, d_tvec0[cur].p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+                                   d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            launch_elim_qr(cur, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+            launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p, nullptr);
         }
     }
 
     // per-point QR, one launch per non-empty track-length bucket (ba_structure: lanes per point x observations per lane)
-    void launch_elim_qr(int which, const T *lam, T *rec, T *dinv, T *tvec, T *tri)
+    void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri, const int *go)
     {
 #define BA_QR(B, L, SLOTS)                                                                                                       \
         if (sx.qr_bucket_ptr[B + 1] > sx.qr_bucket_ptr[B]) {                                                                   \
             const int np_ = sx.qr_bucket_ptr[B + 1] - sx.qr_bucket_ptr[B];                                                       \
             hipLaunchKernelGGL((k_elim_qr<T, L, SLOTS>), dim3(((size_t)np_ * L + 255) / 256), dim3(256), 0, st, np_,           \
-                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc[which].p, d_Jp[which].p, d_r[which].p, lam, rec, dinv, tvec, tri); \
+                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri, go); \
         }
         BA_QR(0, 8, 4)
         BA_QR(1, 16, 4)
@@ -445,7 +460,7 @@ template <typename T> struct Solver final : SolverBase {
             // persistent: schur_wgs workgroups per CU, every wavefront walks its own balanced list of chunks (see k_schur_pairs)
             const dim3 gp(schur_grid);
 #define BA_PAIRS(SC) hipLaunchKernelGGL((k_schur_pairs<T, SC>), gp, dim3(256), 0, st, d_wave_ptr.p, schur_nband, d_chunk_info.p, d_ent.p, d_rec.p, \
-                                        (unsigned)(sizeof(T) * d_rec.n), d_tvec.p, Ml, d_slab.p, d_V[cur].p, d_gc[cur].p, D, ld, d_S.p)
+                                        (unsigned)(sizeof(T) * d_rec.n), d_tvec.p, Ml, d_slab.p, d_V.p, d_gc.p, D, ld, d_S.p)
             // SCALED: CHOLESKY is the only symbol whose point blocks carry a diagonal D (dinv != 1)
             if (kind == BA_CHOLESKY) BA_PAIRS(true); else BA_PAIRS(false);
 #undef BA_PAIRS
@@ -453,7 +468,7 @@ template <typename T> struct Solver final : SolverBase {
         const long long nthr = (long long)nred * BA_SLAB;
         if (nred > 0)
             hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, nred, d_red_pairs.p, D, ld,
-                               d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V[cur].p, d_gc[cur].p, d_S.p);
+                               d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);
     }
 
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
@@ -479,103 +494,98 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (Ml > 0) // (an empty shard keeps the zero partial sums written at creation)
         hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
-                           d_tri.p, d_dxc.p, d_gp[cur].p, d_pts[cur].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1 - cur].p, d_part_bs.p);
-        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[cur].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
-                           d_cam[1 - cur].p, d_scal.p, (int)SC_RHO_C);
+                           d_tri.p, d_dxc.p, d_gp.p, d_pts[0].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1].p, d_part_bs.p);
+        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[0].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
+                           d_cam[1].p, d_scal.p, (int)SC_RHO_C);
     }
 
-    // Everything one trial enqueues after lambda has been set (single shard: no host interaction in between).
-    void launch_trial_kernels()
+    void launch_test_energy()
     {
-        launch_eliminate();
-        launch_schur();
-        launch_post_reduce();
-        launch_factor_solve();
-        launch_backsub_retract();
-        launch_eval(false, 1 - cur);
+        launch_eval(false, 1);
         ba_red_jobs jobs{};
         jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
         jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
         jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
-        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p, (const int *)nullptr);
     }
 
-    // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375)
-    // graph = true (used by minimize on a single shard): the ~110 launches of a trial are captured once per parameter
-    // buffer parity into a hipGraph and replayed; lambda reaches the kernels through device memory.
-    // speculate (minimize, single shard, replayed trials): the linearisation at xTest is enqueued right behind the trial, in
-    // front of the wait for its scalars -- the GPU forms it while the host judges the step and launches the next trial; a
-    // rejected step simply leaves it unused (it lives in the other buffer's set of arrays).
-    int try_step_impl(double lambda_d, double *e_test, double *rho_scale, double *dx_norm, bool graph, bool speculate = false)
+    // sharded: the block-lower trapezoid of S (matrix + rhs row + g_c row: half the bytes of the full buffer) + one tail scalar
+    size_t pack_count() const
+    {
+        const int nbc = Dp / NB;
+        return (size_t)64 * ((size_t)nbc * Dp - (size_t)32 * nbc * (nbc - 1));
+    }
+    int launch_pack(bool unpack)
+    {
+        const size_t npk = pack_count();
+        int rc;
+        if (!d_pack.p && (rc = d_pack.alloc(npk + 1))) return rc;
+        const dim3 gpk((Dp + 255) / 256 > 8 ? 8 : (Dp + 255) / 256, Dp);
+        if (unpack) hipLaunchKernelGGL((k_pack_lower<T, true>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p, npk, d_scal.p, (int)SC_ELOC, (int)SC_ENERGY);
+        else hipLaunchKernelGGL((k_pack_lower<T, false>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p, npk, d_scal.p, (int)SC_ELOC, (int)SC_ENERGY);
+        return BA_OK;
+    }
+
+    // The segments of one trial (everything behind lambda in SC_LAMBDA).  Single shard: A + B back to back; sharded: an
+    // all-reduce of the packed system between A and B and one of the three step scalars behind B.
+    int launch_seg_a() { launch_eliminate(); launch_schur(); return sharded() ? launch_pack(false) : BA_OK; }
+    int launch_seg_b()
+    {
+        int rc;
+        if (sharded() && (rc = launch_pack(true))) return rc;
+        launch_post_reduce();
+        launch_factor_solve();
+        launch_backsub_retract();
+        launch_test_energy();
+        return BA_OK;
+    }
+    // step control on the device, x = xTest and the linearisation of the next outer iteration, the latter two conditional
+    int launch_seg_ctl()
+    {
+        ba_lm_slots sl{sharded() ? SC_ENERGY : SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR};
+        hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(64), 0, st, d_scal.p, d_lm.p, d_log, sl);
+        const int *go = &d_lm.p->go;
+        const int ncam = 15 * N, npts = 3 * Ml;
+        hipLaunchKernelGGL((k_commit<T>), dim3((ncam + npts + 255) / 256), dim3(256), 0, st, ncam, npts, d_cam[1].p, d_pts[1].p, d_cam[0].p, d_pts[0].p, go);
+        return linearize_enqueue(false, go);
+    }
+
+    // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375): the step-level
+    // seam, host-synchronous, with per-phase events (ba_minimize runs the same launches as graphs under device-side control).
+    int try_step(double lambda_d, double *e_test, double *rho_scale, double *dx_norm) override
     {
         int rc;
         if ((rc = set_lambda((T)lambda_d))) return rc;
-        if (graph && world == 1 && !keep) {
-            if (!gexec[cur]) {
-                hipGraph_t g = nullptr;
-                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                launch_trial_kernels();
-                HIPCHK(hipStreamEndCapture(st, &g));
-                HIPCHK(hipGraphInstantiate(&gexec[cur], g, nullptr, nullptr, 0));
-                HIPCHK(hipGraphDestroy(g));
-            }
-            HIPCHK(hipEventRecord(ev[EV_T0], st));
-            HIPCHK(hipGraphLaunch(gexec[cur], st));
-            HIPCHK(hipEventRecord(ev[EV_T6], st));
-            if (speculate) {
-                HIPCHK(hipMemcpyAsync(h_pin, d_scal.p, sizeof(T) * NSCAL, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipEventRecord(ev[EV_F], st));
-                if ((rc = linearize_enqueue(false, 1 - cur))) return rc;
-                HIPCHK(hipEventSynchronize(ev[EV_F]));
-                for (int i = 0; i < NSCAL; i++) h_scal[i] = h_pin[i];
-                if ((rc = check_device_error())) return rc;
-            } else if ((rc = fetch_scalars())) return rc;
-            HIPCHK(hipGetLastError());
-            tm.trial_ms += ev_ms(EV_T0, EV_T6);
-            tm.n_graph_trials++;
-        } else {
-            HIPCHK(hipEventRecord(ev[EV_T0], st));
-            launch_eliminate();
-            HIPCHK(hipEventRecord(ev[EV_T1], st));
-            launch_schur();
-            HIPCHK(hipEventRecord(ev[EV_T2], st));
-            if (world > 1) {
-                // all-reduce only the block-lower trapezoid (matrix + rhs row + g_c row): half the bytes of the full buffer
-                const int nbc = Dp / NB;
-                const size_t npk = (size_t)64 * ((size_t)nbc * Dp - (size_t)32 * nbc * (nbc - 1));
-                if (!d_pack.p && (rc = d_pack.alloc(npk))) return rc;
-                const dim3 gpk((Dp + 255) / 256 > 8 ? 8 : (Dp + 255) / 256, Dp);
-                hipLaunchKernelGGL((k_pack_lower<T, false>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p);
-                if ((rc = allreduce(d_pack.p, npk, 0))) return rc;
-                hipLaunchKernelGGL((k_pack_lower<T, true>), gpk, dim3(256), 0, st, Dp, ld, d_S.p, d_pack.p);
-            }
-            launch_post_reduce();
-            if (keep) {
-                if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
-                HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
-            }
-            HIPCHK(hipEventRecord(ev[EV_T3], st));
-            launch_factor_solve();
-            HIPCHK(hipEventRecord(ev[EV_T4], st));
-            launch_backsub_retract();
-            HIPCHK(hipEventRecord(ev[EV_T5], st));
-            launch_eval(false, 1 - cur);
-            ba_red_jobs jobs{};
-            jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
-            jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
-            jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
-            hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p);
-            HIPCHK(hipEventRecord(ev[EV_T6], st));
-            if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
-            if ((rc = fetch_scalars())) return rc;
-            HIPCHK(hipGetLastError());
-            tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
-            tm.schur_ms += ev_ms(EV_T1, EV_T2);
-            tm.factor_ms += ev_ms(EV_T3, EV_T4);
-            tm.backsub_ms += ev_ms(EV_T4, EV_T5);
-            tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
-            tm.trial_ms += ev_ms(EV_T0, EV_T6);
+        HIPCHK(hipEventRecord(ev[EV_T0], st));
+        launch_eliminate();
+        HIPCHK(hipEventRecord(ev[EV_T1], st));
+        launch_schur();
+        HIPCHK(hipEventRecord(ev[EV_T2], st));
+        if (sharded()) {
+            if ((rc = launch_pack(false)) || (rc = allreduce(d_pack.p, pack_count() + 1, 0)) || (rc = launch_pack(true))) return rc;
         }
+        HIPCHK(hipEventRecord(ev[EV_T3], st));
+        launch_post_reduce();
+        if (keep) {
+            if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
+            HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
+        }
+        launch_factor_solve();
+        HIPCHK(hipEventRecord(ev[EV_T4], st));
+        launch_backsub_retract();
+        HIPCHK(hipEventRecord(ev[EV_T5], st));
+        launch_test_energy();
+        HIPCHK(hipEventRecord(ev[EV_T6], st));
+        if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
+        if ((rc = fetch_scalars())) return rc;
+        HIPCHK(hipGetLastError());
+        tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
+        tm.schur_ms += ev_ms(EV_T1, EV_T2);
+        tm.comm_ms += ev_ms(EV_T2, EV_T3);
+        tm.factor_ms += ev_ms(EV_T3, EV_T4);
+        tm.backsub_ms += ev_ms(EV_T4, EV_T5);
+        tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
+        tm.trial_ms += ev_ms(EV_T0, EV_T6);
         tm.n_trials++;
         if (e_test) *e_test = (double)h_scal[SC_ETEST];
         if (rho_scale) *rho_scale = (double)(h_scal[SC_RHO_P] + h_scal[SC_RHO_C]);
@@ -584,22 +594,21 @@ template <typename T> struct Solver final : SolverBase {
         return BA_OK;
     }
 
-    int try_step(double lambda_d, double *e_test, double *rho_scale, double *dx_norm) override
-    {
-        return try_step_impl(lambda_d, e_test, rho_scale, dx_norm, false);
-    }
-
+    // x = xTest (BacktrackLevMarqQRChol.h:428)
     int accept() override
     {
         if (!have_step) return BA_ERR_ARG;
-        cur = 1 - cur;
+        const int ncam = 15 * N, npts = 3 * Ml;
+        hipLaunchKernelGGL((k_commit<T>), dim3((ncam + npts + 255) / 256), dim3(256), 0, st, ncam, npts, d_cam[1].p, d_pts[1].p, d_cam[0].p, d_pts[0].p,
+                           (const int *)nullptr);
+        HIPCHK(hipStreamSynchronize(st));
         have_step = false;
         return BA_OK;
     }
 
     int stats(double *out4) override
     {
-        hipLaunchKernelGGL((k_stats<T>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[cur].p, d_pts[cur].p, d_obs_cam.p,
+        hipLaunchKernelGGL((k_stats<T>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[0].p, d_pts[0].p, d_obs_cam.p,
                            d_obs_pt.p, d_meas.p, tau, d_part_st.p);
         ba_red_jobs jobs{};
         for (int q = 0; q < 4; q++) jobs.j[q] = {d_part_st.p + (size_t)q * gK, gK, 0, SC_ST0 + q};
@@ -631,28 +640,28 @@ template <typename T> struct Solver final : SolverBase {
         switch (what) {
         case BA_GET_RESIDUALS: {
             if (n != 2 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_r[cur].p, 2 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_r.p, 2 * (size_t)Kl, h))) return rc;
             // file order inside the shard when the input was sorted; sorted order otherwise (perm documents it)
             for (int i = 0; i < Kl; i++) { out[2 * (size_t)i] = h[i]; out[2 * (size_t)i + 1] = h[(size_t)Kl + i]; }
             return BA_OK;
         }
         case BA_GET_JC: {
             if (n != 18 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_Jc[cur].p, 18 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_Jc.p, 18 * (size_t)Kl, h))) return rc;
             for (int i = 0; i < Kl; i++)
                 for (int q = 0; q < 18; q++) out[18 * (size_t)i + q] = h[(size_t)q * Kl + i];
             return BA_OK;
         }
         case BA_GET_JP: {
             if (n != 6 * (size_t)Kl) return BA_ERR_ARG;
-            if ((rc = dl(d_Jp[cur].p, 6 * (size_t)Kl, h))) return rc;
+            if ((rc = dl(d_Jp.p, 6 * (size_t)Kl, h))) return rc;
             for (int i = 0; i < Kl; i++)
                 for (int q = 0; q < 6; q++) out[6 * (size_t)i + q] = h[(size_t)q * Kl + i];
             return BA_OK;
         }
         case BA_GET_GRAD: {
             if (n != 3 * (size_t)Ml + D) return BA_ERR_ARG;
-            if ((rc = dl(d_gp[cur].p, 3 * (size_t)Ml, h)) || (rc = dl(d_gc[cur].p, D, h2))) return rc;
+            if ((rc = dl(d_gp.p, 3 * (size_t)Ml, h)) || (rc = dl(d_gc.p, D, h2))) return rc;
             for (int j = 0; j < Ml; j++)
                 for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
             for (int c = 0; c < D; c++) out[3 * (size_t)Ml + c] = h2[c];
@@ -683,7 +692,7 @@ template <typename T> struct Solver final : SolverBase {
         case BA_GET_CAMS:
         case BA_GET_CAMS_TEST: {
             if (n != 15 * (size_t)N) return BA_ERR_ARG;
-            if ((rc = dl(d_cam[what == BA_GET_CAMS ? cur : 1 - cur].p, 15 * (size_t)N, h))) return rc;
+            if ((rc = dl(d_cam[what == BA_GET_CAMS ? 0 : 1].p, 15 * (size_t)N, h))) return rc;
             for (int a = 0; a < N; a++)
                 for (int q = 0; q < 15; q++) out[15 * (size_t)a + q] = h[(size_t)q * N + a];
             return BA_OK;
@@ -691,7 +700,7 @@ template <typename T> struct Solver final : SolverBase {
         case BA_GET_POINTS:
         case BA_GET_POINTS_TEST: {
             if (n != 3 * (size_t)Ml) return BA_ERR_ARG;
-            if ((rc = dl(d_pts[what == BA_GET_POINTS ? cur : 1 - cur].p, 3 * (size_t)Ml, h))) return rc;
+            if ((rc = dl(d_pts[what == BA_GET_POINTS ? 0 : 1].p, 3 * (size_t)Ml, h))) return rc;
             for (int j = 0; j < Ml; j++)
                 for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
             return BA_OK;
@@ -707,115 +716,191 @@ template <typename T> struct Solver final : SolverBase {
             std::vector<T> h((size_t)15 * N);
             for (int a = 0; a < N; a++)
                 for (int q = 0; q < 15; q++) h[(size_t)q * N + a] = (T)cam15[15 * (size_t)a + q];
-            HIPCHK(hipMemcpy(d_cam[cur].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_cam[0].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
         }
         if (pts && Ml > 0) {
             std::vector<T> h((size_t)3 * Ml);
             for (int j = 0; j < Ml; j++)
                 for (int q = 0; q < 3; q++) h[(size_t)q * Ml + j] = (T)pts[3 * (size_t)j + q];
-            HIPCHK(hipMemcpy(d_pts[cur].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_pts[0].p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
         }
         have_step = false;
         return BA_OK;
     }
 
-    // The LM loop: BacktrackLevMarqQRChol.h:204-436 == BacktrackLevMarqCholesky.h:190-361 (Scalar arithmetic in T).
+    // ---- the LM loop: BacktrackLevMarqQRChol.h:204-436 == BacktrackLevMarqCholesky.h:190-361 (Scalar arithmetic in T) ------------
+    // The first outer iteration is linearised host-synchronously (lambda0 needs max diag J'J); from then on the host only ENQUEUES:
+    // every trial is the captured segments + k_lm_control, which decides accept / rho / lambda / flat-line on the device and gates
+    // x = xTest and the next linearisation.  The host keeps at most LM_DEPTH trials in the stream, watches the progress counter
+    // the control kernel bumps in pinned memory, and prints / forwards the table rows as they appear there.
+    static constexpr int LM_DEPTH = 3;
+
+    int capture(hipGraphExec_t *g, int (Solver::*seg)())
+    {
+        if (*g) return BA_OK;
+        hipGraph_t gr = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = (this->*seg)();
+        const hipError_t e = hipStreamEndCapture(st, &gr); // (also on the error path: never leave the stream capturing)
+        if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+        if (e != hipSuccess) { fprintf(stderr, "ba_mi355x: hipStreamEndCapture: %s\n", hipGetErrorString(e)); return BA_ERR_HIP; }
+        const hipError_t ei = hipGraphInstantiate(g, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (ei != hipSuccess) { *g = nullptr; return BA_ERR_HIP; }
+        return BA_OK;
+    }
+    int launch_seg_ab() { int rc = launch_seg_a(); return rc ? rc : launch_seg_b(); }
+
+    // one segment: replay its graph, or (legacy stream, BA_NO_GRAPH, sharding through a host callback) launch it directly
+    int run_seg(hipGraphExec_t *g, int (Solver::*seg)(), bool graphs)
+    {
+        if (!graphs) return (this->*seg)();
+        int rc = capture(g, seg);
+        if (rc) return rc;
+        HIPCHK(hipGraphLaunch(*g, st));
+        return BA_OK;
+    }
+
+    int enqueue_trial(int slot, bool graphs)
+    {
+        int rc;
+        EvSlot &e = ring[slot];
+        HIPCHK(hipEventRecord(e.e[0], st));
+        if (!sharded()) {
+            if ((rc = run_seg(&g_trial, &Solver::launch_seg_ab, graphs))) return rc;
+            HIPCHK(hipEventRecord(e.e[1], st));
+            HIPCHK(hipEventRecord(e.e[2], st));
+            HIPCHK(hipEventRecord(e.e[3], st));
+        } else {
+            if ((rc = run_seg(&g_a, &Solver::launch_seg_a, graphs))) return rc;
+            HIPCHK(hipEventRecord(e.e[1], st));
+            if ((rc = allreduce(d_pack.p, pack_count() + 1, 0))) return rc; // reduced camera system + rhs + g_c + energy tail
+            HIPCHK(hipEventRecord(e.e[2], st));
+            if ((rc = run_seg(&g_b, &Solver::launch_seg_b, graphs))) return rc;
+            HIPCHK(hipEventRecord(e.e[3], st));
+            if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;     // test energy, rho denominator, |dx|^2 (point parts)
+        }
+        HIPCHK(hipEventRecord(e.e[4], st));
+        if ((rc = run_seg(&g_ctl, &Solver::launch_seg_ctl, graphs))) return rc;
+        HIPCHK(hipEventRecord(e.e[5], st));
+        return BA_OK;
+    }
+
+    void harvest(int slot, bool accepted)
+    {
+        EvSlot &e = ring[slot];
+        tm.trial_ms += ev_ms(e.e[0], e.e[4]);
+        tm.comm_ms += ev_ms(e.e[1], e.e[2]) + ev_ms(e.e[3], e.e[4]);
+        tm.n_trials++;
+        tm.n_graph_trials++;
+        if (accepted) { tm.linearize_ms += ev_ms(e.e[4], e.e[5]); tm.n_linearize++; }
+    }
+
     int minimize(const ba_lm_params *lmp, ba_trial_cb cb, void *user, ba_result *out) override
     {
         ba_lm_params lm;
         if (lmp) lm = *lmp; else ba_lm_params_default(&lm);
         const auto tbeg = std::chrono::steady_clock::now();
-        ba_timing tm0 = tm;
-        if (lm.verbose && rank == 0) {
+        const ba_timing tm0 = tm;
+        const bool talk = lm.verbose && rank == 0;
+        if (talk) {
             // outputHeader / outputIterHeader, BacktrackLevMarqQRChol.h:65-82
             printf("############################## Backtrack LevMarq ###############################\n");
             printf("--------------------------------------------------------------------------------\n");
             printf(" Iter%15s%15s%15s%15s%15s\n", "Status", "f", "rho", "lambda", "Elapsed");
             printf("--------------------------------------------------------------------------------\n");
         }
-        T lambda = (T)lm.lambda_init, lambda_inc = (T)lm.lambda_increase_base;
-        const T lam_min = (T)lm.lambda_min, lam_max = (T)lm.lambda_max, tol_fun = (T)lm.tol_fun;
-        T hist[2] = {0, 0}, energy = 0;
-        int fun_evals = 0, iter = 0, trials = 0, status = BA_RUNNING, rc = BA_OK;
-        bool stop = false, lin_pending = false;
-        while (true) {
-            iter++;
-            if (iter > lm.max_iter) { status = BA_MAX_ITERS; break; }
-            if (fun_evals > lm.max_fun_ev) { status = BA_TOO_MANY_FUN_EVALS; break; }
+        int rc = BA_OK;
+        ba_lm_dev<T> h{};
+        h.lam_min = (T)lm.lambda_min; h.lam_max = (T)lm.lambda_max; h.tol_fun = (T)lm.tol_fun; h.inc_base = (T)lm.lambda_increase_base;
+        h.lambda = (T)lm.lambda_init; h.lambda_inc = h.inc_base;
+        h.max_iter = lm.max_iter; h.max_fun_ev = lm.max_fun_ev; h.max_trials = lm.max_trials;
+        h.status = BA_RUNNING;
+        h.iter = 1;
+        int launched = 0, consumed = 0, harvested = 0;
+        std::vector<char> acc_of(RING_EV, 0);
+        if (h.iter > lm.max_iter) { h.status = BA_MAX_ITERS; h.stop = 1; }
+        else if (lm.max_trials < 0) { h.stop = 1; }
+        else {
+            // outer iteration 1: m_functor(x, r), df, JtRes, column norms; lambda0 = 1e-12 max diag J'J (:257-280; Cholesky.h:263-265);
+            // MOREQR: 1e-6 * max column norm (BacktrackLevMarqMore.h:272-284)
             double e = 0, dmax = 0;
-            // after an accepted step of a single-shard run the linearisation is already in the stream (try_step_impl, speculate);
-            // its energy (== the test energy of that step, evaluated by the same code at the same point) is read back together
-            // with the next trial
-            const bool lin_spec = iter > 1 && world == 1 && use_graph && !keep;
-            // sharded run: no speculation (the trial is not replayed), but the linearisation and the all-reduce of its energy
-            // are only enqueued as well -- the energy comes back with the scalars of the next trial, one host
-            // synchronisation per LM iteration instead of two
-            const bool lin_async = lin_spec || (iter > 1 && world > 1 && !keep);
-            if (lin_spec) {
-                // (already enqueued behind the accepted trial, speculatively, for the buffer that is now the current one)
-            } else if (lin_async) {
-                if ((rc = linearize_enqueue(false)) || (rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) break;
-            } else {
-                if ((rc = linearize(&e, iter == 1 ? &dmax : nullptr))) break;
-                energy = (T)e;
-            }
-            lin_pending = lin_async;
-            fun_evals++;
-            if (iter == 1) // :278-280 / Cholesky.h:263-265; MOREQR: 1e-6 * max column norm (BacktrackLevMarqMore.h:272-284)
-                lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
-            while (true) {
-                if (lm.max_trials > 0 && trials >= lm.max_trials) { stop = true; status = BA_RUNNING; break; }
-                const auto t0 = std::chrono::steady_clock::now();
-                double et = 0, rs = 0, dn = 0;
-                if ((rc = try_step_impl((double)lambda, &et, &rs, &dn, use_graph, world == 1 && use_graph && !keep))) { stop = true; break; }
-                if (lin_pending) { energy = h_scal[SC_ENERGY]; linearize_account(); lin_pending = false; }
-                fun_evals++;
-                const T e_test = (T)et;
-                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                trials++;
-                if (e_test < energy) {
-                    const T rho = (energy - e_test) / (T)rs;
-                    const T tmv = (T)2.0 * rho - (T)1.0;
-                    const T mul = (T)1.0 - tmv * tmv * tmv;
-                    lambda *= std::max<T>((T)1.0 / (T)3.0, mul);
-                    lambda = std::max<T>(lambda, lam_min);
-                    if (cb) cb(user, iter, 1, (double)energy, (double)rho, (double)lambda, el);
-                    if (lm.verbose && rank == 0)
-                        printf("%5d%15s%15g%15g%15g%14gs\n", iter, "Accepted", (double)energy, (double)rho, (double)lambda, el);
-                    lambda_inc = (T)lm.lambda_increase_base;
-                    energy = e_test;
-                    hist[iter % 2] = energy;
-                    break;
-                } else {
-                    if (cb) cb(user, iter, 0, (double)energy, 0.0, (double)lambda, el);
-                    if (lm.verbose && rank == 0)
-                        printf("%5d%15s%15g%15g%15g%14gs\n", iter, "Rejected", (double)energy, 0.0, (double)lambda, el);
-                    if (lambda > lam_max) { status = BA_EXCEEDED_LAMBDA_MAX; stop = true; break; }
-                    lambda *= lambda_inc;
-                    lambda_inc = std::pow(lambda_inc, (T)1.5);
+            if ((rc = linearize(&e, &dmax))) return rc;
+            h.energy = (T)e;
+            h.fun_evals = 1;
+            h.lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
+        }
+        if (!h.stop && sharded() && !d_pack.p && (rc = d_pack.alloc(pack_count() + 1))) return rc; // (never inside a stream capture)
+        if (!h.stop) {
+            h_log->done = 0; h_log->stop = 0; h_log->status = BA_RUNNING;
+            if ((rc = set_lambda(h.lambda))) return rc;
+            HIPCHK(hipMemcpyAsync(d_lm.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st)); // (h is on the stack)
+            // graphs unless the stream cannot be captured (legacy stream) or a host callback sits between the segments anyway
+            const bool graphs = use_graph && st != nullptr;
+            auto tlast = std::chrono::steady_clock::now();
+            auto drain = [&]() { // table rows that have appeared since the last look
+                const int done = __atomic_load_n(&h_log->done, __ATOMIC_ACQUIRE);
+                while (consumed < done) {
+                    const ba_lm_row r = h_log->rows[consumed % BA_LM_RING];
+                    const auto tnow = std::chrono::steady_clock::now();
+                    const double el = std::chrono::duration<double>(tnow - tlast).count();
+                    tlast = tnow;
+                    acc_of[consumed % RING_EV] = r.accepted != 0;
+                    if (cb) cb(user, (int)r.iter, (int)r.accepted, r.f, r.rho, r.lambda, el);
+                    if (talk) // outputIter, BacktrackLevMarqQRChol.h:84-93 (f is the energy BEFORE the step)
+                        printf("%5d%15s%15g%15g%15g%14gs\n", (int)r.iter, r.accepted != 0 ? "Accepted" : "Rejected", r.f, r.rho, r.lambda, el);
+                    consumed++;
                 }
+                while (harvested + 1 < consumed) { harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; } // (its events are complete)
+                return done;
+            };
+            auto tprog = std::chrono::steady_clock::now(); // last time the device made progress (a trial finished)
+            int seen = 0;
+            while (true) {
+                const int done = drain();
+                if (done != seen) { seen = done; tprog = std::chrono::steady_clock::now(); }
+                if (__atomic_load_n(&h_log->stop, __ATOMIC_ACQUIRE)) break;
+                const bool all_in = lm.max_trials > 0 && launched >= lm.max_trials;
+                if (all_in && done >= launched) break; // (the device has set `stop` by then; belt and braces)
+                if (!all_in && launched - done < LM_DEPTH) {
+                    if ((rc = enqueue_trial(launched % RING_EV, graphs))) break;
+                    launched++;
+                    continue;
+                }
+                // LM_DEPTH trials are in the stream: wait for a row (a trial is 0.1 ... 20 ms; ten minutes without one = a hung kernel)
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tprog).count() > 600.0) {
+                    fprintf(stderr, "ba_mi355x: no LM trial completed within 600 s\n");
+                    rc = BA_ERR_HIP;
+                    break;
+                }
+                __builtin_ia32_pause();
             }
-            if (stop) break;
-            if (iter > 2) {
-                const T maxf = std::max(hist[0], hist[1]);
-                if (std::fabs(energy - maxf) < tol_fun * energy) { status = BA_SUCCESS; break; } // before x = xTest (:419-428)
+            const hipError_t es = hipStreamSynchronize(st);
+            if (es != hipSuccess) { fprintf(stderr, "ba_mi355x: %s\n", hipGetErrorString(es)); return BA_ERR_HIP; }
+            drain();
+            while (harvested < consumed) { harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; }
+            if (rc) return rc;
+            HIPCHK(hipMemcpy(&h, d_lm.p, sizeof h, hipMemcpyDeviceToHost));
+            if (h.fresh) { // stopped (max_trials) right behind an accepted step: the energy of the linearisation that followed it
+                if ((rc = fetch_scalars())) return rc;
+                if (sharded()) { // (only this shard's part is there until a trial carries it through the all-reduce)
+                    HIPCHK(hipMemcpyAsync(d_scal.p + SC_ENERGY, d_scal.p + SC_ELOC, sizeof(T), hipMemcpyDeviceToDevice, st));
+                    if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0)) || (rc = fetch_scalars())) return rc;
+                }
+                h.energy = h_scal[SC_ENERGY];
             }
-            if ((rc = accept())) break;
+            if (h.status == BA_DEV_FAILED) { report_device_error(h.deverr); return BA_ERR_HIP; }
+            HIPCHK(hipGetLastError());
         }
-        if (lin_pending && !rc) { // stopped by max_trials right behind an enqueued linearisation
-            if (!(rc = fetch_scalars())) { energy = h_scal[SC_ENERGY]; linearize_account(); }
-        }
-        if (lm.verbose && rank == 0) printf("--------------------------------------------------------------------------------\n");
+        if (talk) printf("--------------------------------------------------------------------------------\n");
+        have_step = false;
         if (out) {
-            out->status = status; out->iterations = iter; out->trials = trials; out->fun_evals = fun_evals;
-            out->energy = (double)energy; out->lambda = (double)lambda;
+            out->status = h.status; out->iterations = h.iter; out->trials = h.trials; out->fun_evals = h.fun_evals;
+            out->energy = (double)h.energy; out->lambda = (double)h.lambda;
             out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tbeg).count();
-            const long long nt = tm.n_trials - tm0.n_trials, nl = tm.n_linearize - tm0.n_linearize;
-            const long long ng = tm.n_graph_trials - tm0.n_graph_trials;
-            // graph replay: only the whole trial is timed (it includes the ~20 us test-energy evaluation)
-            out->schur_ms = !nt ? 0.0 : ng == nt ? (tm.trial_ms - tm0.trial_ms) / nt
-                                : ((tm.eliminate_ms - tm0.eliminate_ms) + (tm.schur_ms - tm0.schur_ms) + (tm.factor_ms - tm0.factor_ms) +
-                                   (tm.backsub_ms - tm0.backsub_ms)) / (nt - ng > 0 ? nt - ng : 1);
+            const long long nt = tm.n_graph_trials - tm0.n_graph_trials, nl = tm.n_linearize - tm0.n_linearize;
+            out->schur_ms = nt ? (tm.trial_ms - tm0.trial_ms) / nt : 0.0; // whole trial incl. the test-energy evaluation and the all-reduces
             out->linearize_ms = nl ? (tm.linearize_ms - tm0.linearize_ms) / nl : 0.0;
         }
         return rc;
@@ -845,8 +930,8 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T0], st));
         for (int k = 0; k < reps; k++) {
             switch (phase) {
-            case 0: launch_eval(false, cur); break;
-            case 1: launch_eval(true, cur); launch_grad(cur); break;
+            case 0: launch_eval(false, 0); break;
+            case 1: launch_eval(true, 0); launch_grad(); break;
             case 2: launch_eliminate(); break;
             case 3: launch_schur(); break;
             case 4:
@@ -940,6 +1025,13 @@ int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user)
     if (!s) return BA_ERR_ARG;
     s->impl->ar_fn = fn; s->impl->ar_user = user;
     return BA_OK;
+}
+
+int ba_solver_comm_init(ba_solver *s, const void *id)
+{
+    if (!s || !id) return BA_ERR_ARG;
+    if (s->impl->comm) return BA_ERR_ARG;
+    return ba_rccl_init(&s->impl->comm, id, s->impl->rank, s->impl->world);
 }
 
 int ba_solver_set_stream(ba_solver *s, void *hip_stream)

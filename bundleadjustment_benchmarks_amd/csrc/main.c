@@ -4,7 +4,10 @@
  * solver symbol (-DQRKIT / -DQRCHOL / -DCHOLESKY / -DMOREQR, src/CMakeLists.txt:95-178); -DBA_SCALAR_FLOAT stands for
  * `typedef float Scalar;` (src/BATypeUtils.h:6-7).  All work happens behind the C ABI of include/ba_mi355x.h.
  * Extensions: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking);
- * BA_CACHE=1 keeps a binary cache `<file>.bacache` of the parsed problem and reuses it when present.
+ * BA_CACHE=1 keeps a binary cache `<file>.bacache` of the parsed problem and reuses it when present;
+ * BA_WORLD / BA_RANK (one process per GPU of a node, started by hand or by a launcher; BA_DEVICE defaults to BA_RANK) shard the
+ * points over the processes, which meet through the file BA_COMM_FILE (default /tmp/ba_mi355x_comm.id, written by rank 0) and
+ * then all-reduce the reduced camera system over RCCL inside the library; rank 0 prints.
  */
 #define _POSIX_C_SOURCE 199309L
 #include "../../include/ba_mi355x.h"
@@ -66,23 +69,45 @@ int main(int argc, char *argv[])
     }
     int N, M, K;
     ba_problem_dims(p, &N, &M, &K);
-    printf("N(cameras) = %d, M(points) = %d, K(measurements) = %d\n", N, M, K);
-    printf("Reading image measurements...\nDone.\n");
-    printf("Reading cameras params...\nDone.\n");
-    printf("Reading 3D points...\nDone.\n");
+    const int world = getenv("BA_WORLD") ? atoi(getenv("BA_WORLD")) : 1, rank = getenv("BA_RANK") ? atoi(getenv("BA_RANK")) : 0;
+    if (world < 1 || rank < 0 || rank >= world) {
+        fprintf(stderr, "BA_WORLD / BA_RANK: need 0 <= rank < world\n");
+        ba_problem_free(p);
+        return BA_ERR_USAGE;
+    }
+    const int talk = rank == 0;
+    if (talk) {
+        printf("N(cameras) = %d, M(points) = %d, K(measurements) = %d\n", N, M, K);
+        printf("Reading image measurements...\nDone.\n");
+        printf("Reading cameras params...\nDone.\n");
+        printf("Reading 3D points...\nDone.\n");
+    }
 
     ba_solver *s = NULL;
-    rc = ba_solver_create(p, BA_KIND, BA_SCALAR, -1, 0, 1, &s);
+    const int device = getenv("BA_DEVICE") ? atoi(getenv("BA_DEVICE")) : (world > 1 ? rank : -1);
+    rc = ba_solver_create(p, BA_KIND, BA_SCALAR, device, rank, world, &s);
     if (rc != BA_OK) {
         fprintf(stderr, "ba_solver_create: %s\n", ba_error_string(rc));
         ba_problem_free(p);
         return rc;
     }
-    show_stats(s, K);
+    if (world > 1) { /* RCCL inside the library; the communicator id travels through a file */
+        unsigned char id[BA_COMM_ID_BYTES];
+        const char *idf = getenv("BA_COMM_FILE") ? getenv("BA_COMM_FILE") : "/tmp/ba_mi355x_comm.id";
+        rc = ba_comm_id_via_file(idf, rank, id);
+        if (rc == BA_OK) rc = ba_solver_comm_init(s, id);
+        if (rc != BA_OK) {
+            fprintf(stderr, "communicator set-up (rank %d of %d, %s): %s\n", rank, world, idf, ba_error_string(rc));
+            ba_solver_free(s);
+            ba_problem_free(p);
+            return rc;
+        }
+    }
+    if (talk) show_stats(s, K); else { double st_[4]; (void)ba_solver_stats(s, st_); } /* (the statistics are a collective) */
 
     ba_lm_params lm;
     ba_lm_params_default(&lm);
-    lm.verbose = 1;
+    lm.verbose = talk;
     if (getenv("BA_MAX_TRIALS")) lm.max_trials = atoi(getenv("BA_MAX_TRIALS"));
     ba_result res;
     struct timespec t0, t1;
@@ -95,10 +120,14 @@ int main(int argc, char *argv[])
         ba_problem_free(p);
         return rc;
     }
-    printf("lm.minimize(params) ... %gs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
-    printf("LM finished with status: %s\n", ba_status_string(res.status));
-
-    show_stats(s, K);
+    if (talk) {
+        printf("lm.minimize(params) ... %gs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+        printf("LM finished with status: %s\n", ba_status_string(res.status));
+        show_stats(s, K);
+    } else {
+        double st_[4];
+        (void)ba_solver_stats(s, st_);
+    }
     ba_solver_free(s);
     ba_problem_free(p);
     return BA_OK; /* success even if the LM status is not Success, like the reference (:175) */

@@ -119,9 +119,21 @@ typedef struct {
 typedef void (*ba_trial_cb)(void *user, int iter, int accepted, double f, double rho, double lambda, double elapsed_s);
 
 /* Sum (op 0) or max (op 1) all-reduce of `count` scalars of type `scalar` in DEVICE memory across the ranks that
- * shard one problem; called on the host thread between kernels, `stream` is the hipStream_t the solver enqueues on.
- * Supplied by the host layer (torch.distributed / RCCL); never called when shard_world == 1. */
+ * shard one problem; called on the host thread between kernels, `stream` is the hipStream_t the solver enqueues on (the
+ * callback must order itself against that stream).  A transport supplied by the host layer -- used by the gloo tests; the
+ * production transport is RCCL inside the library (ba_solver_comm_init).  Never called when shard_world == 1. */
 typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scalar, int op, void *stream);
+
+/* ---- communication of a sharded solve (no reference counterpart: the reference is one process) ------------------------- */
+
+/* RCCL inside the library.  ba_comm_unique_id: rank 0 creates the 128-byte id of a new communicator (ncclGetUniqueId); the host
+ * layer carries it to the other ranks (torch.distributed / MPI / a file: ba_comm_id_via_file); then EVERY rank of the shard
+ * group calls ba_solver_comm_init (collective: ncclCommInitRank with the solver's shard_rank / shard_world, on the solver's
+ * device).  From then on the per-trial all-reduces of the packed reduced camera system and of the step scalars are
+ * ncclAllReduce calls on the solver's stream, enqueued by ba_minimize without a host synchronisation. */
+#define BA_COMM_ID_BYTES 128
+int ba_comm_unique_id(void *id_out /* BA_COMM_ID_BYTES */);
+int ba_comm_id_via_file(const char *path, int rank, void *id_out); /* rank 0 writes the id (atomic rename), the others wait for it */
 
 /* Replaces the construction of BAFunctor + the LM object (bundle_adjustment_large.cpp:117-131): copies the problem
  * to HBM in SoA layout, builds the static camera-pair structure.  Points (and their observations) are partitioned
@@ -131,7 +143,8 @@ typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scal
 int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar, int device, int shard_rank,
                      int shard_world, ba_solver **out);
 void ba_solver_free(ba_solver *s);
-int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user);
+int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user); /* host-language transport (gloo tests); RCCL: next line */
+int ba_solver_comm_init(ba_solver *s, const void *id /* BA_COMM_ID_BYTES, from ba_comm_unique_id on rank 0 */);
 /* Enqueue on a caller-owned hipStream_t (e.g. torch's current stream) instead of the solver's own stream. */
 int ba_solver_set_stream(ba_solver *s, void *hip_stream);
 /* Point range [p0,p1) and observation range [o0,o1) owned by this shard. */
@@ -181,8 +194,8 @@ typedef struct {
     double factor_ms;     /* dense LDL^T + triangular solves */
     double backsub_ms;    /* point back-substitution + retraction */
     double test_eval_ms;  /* residual at xTest + scalar reductions */
-    double comm_ms;       /* host wall time spent inside the all-reduce callback */
-    double trial_ms;      /* whole trial, device time (the only per-trial figure when the trial is replayed as a hipGraph) */
+    double comm_ms;       /* device time of the all-reduces (HIP events around them on the solver's stream) */
+    double trial_ms;      /* whole trial, device time (the only per-trial figure when the trial is replayed as hipGraphs) */
     long long n_linearize, n_trials, n_graph_trials;
 } ba_timing;
 int ba_solver_timing(ba_solver *s, ba_timing *out, int reset);

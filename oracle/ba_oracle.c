@@ -45,6 +45,16 @@ int ora_bal_read(const char *path, int N, int M, int K, int *cam_idx, int *pt_id
     return 0;
 }
 
+/* Threads of the OpenMP loops (the dense factorisation's trailing update): 1 = the reference's own single-threaded regime. */
+#if defined(_OPENMP)
+#include <omp.h>
+void ora_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+int ora_max_threads(void) { return omp_get_max_threads(); }
+#else
+void ora_set_threads(int n) { (void)n; }
+int ora_max_threads(void) { return 1; }
+#endif
+
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 

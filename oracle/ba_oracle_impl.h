@@ -242,23 +242,48 @@ void FN(ora_stats)(int N, int M, int K, const S *cam15, const S *pts, const int 
  * No pivoting, no sqrt: survives small negative pivots like SimplicialLDLT does. */
 static void FN(dense_ldlt)(int n, S *A)
 {
-    S *w = (S *)malloc(sizeof(S) * (size_t)n);
-    for (int j = 0; j < n; j++) {
-        /* left-looking: w[k] = L[j][k]*D[k] */
-        S d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; k++) {
-            w[k] = A[(size_t)k * n + j] * A[(size_t)k * n + k];
-            d -= A[(size_t)k * n + j] * w[k];
+    /* Blocked right-looking form (64-wide panels; the trailing update is the only loop OpenMP splits, by columns).  Every
+     * element still receives its updates in ascending pivot order with the products formed as L(i,k) * (L(j,k) D(k)), so the
+     * result is bit-identical to the plain left-looking column loop this replaced (and to itself for any thread count):
+     * the committed fixtures of the oracle's trajectories stay valid.  It is here for the CPU baseline's sake -- the
+     * unblocked loop re-read the whole factor for every column (1.3 LM it/s at config 4). */
+    enum { PB = 64 };
+    S *w = (S *)malloc(sizeof(S) * (size_t)PB * (size_t)n); /* w[(k - j0) * n + c] = L(c,k) D(k) */
+    for (int j0 = 0; j0 < n; j0 += PB) {
+        const int j1 = j0 + PB < n ? j0 + PB : n;
+        /* panel: columns j0..j1-1, updates by the panel's own earlier columns only (earlier panels have been applied) */
+        for (int j = j0; j < j1; j++) {
+            S *col = A + (size_t)j * n;
+            S d = col[j];
+            for (int k = j0; k < j; k++) {
+                const S wk = A[(size_t)k * n + j] * A[(size_t)k * n + k];
+                w[(size_t)(k - j0) * n + j] = wk;
+                d -= A[(size_t)k * n + j] * wk;
+            }
+            col[j] = d;
+            for (int k = j0; k < j; k++) {
+                const S wk = w[(size_t)(k - j0) * n + j];
+                const S *ck = A + (size_t)k * n;
+                for (int i = j + 1; i < n; i++) col[i] -= ck[i] * wk;
+            }
+            const S inv = (S)1.0 / d;
+            for (int i = j + 1; i < n; i++) col[i] *= inv;
         }
-        A[(size_t)j * n + j] = d;
-        S *col = A + (size_t)j * n;
-        for (int k = 0; k < j; k++) {
-            const S wk = w[k];
-            const S *ck = A + (size_t)k * n;
-            for (int i = j + 1; i < n; i++) col[i] -= ck[i] * wk;
+        /* trailing update of the columns behind the panel */
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 8) if (n - j1 > 256)
+#endif
+        for (int c = j1; c < n; c++) {
+            S *col = A + (size_t)c * n;
+            S d = col[c];
+            for (int k = j0; k < j1; k++) {
+                const S *ck = A + (size_t)k * n;
+                const S wk = ck[c] * ck[k];
+                d -= ck[c] * wk;
+                for (int i = c + 1; i < n; i++) col[i] -= ck[i] * wk;
+            }
+            col[c] = d;
         }
-        const S inv = (S)1.0 / d;
-        for (int i = j + 1; i < n; i++) col[i] *= inv;
     }
     free(w);
 }

@@ -34,11 +34,17 @@ def lib():
         _lib = C.CDLL(build())
         _lib.ora_residuals_f64.restype = C.c_double
         _lib.ora_residuals_f32.restype = C.c_float
+        _lib.ora_set_threads(1)  # the reference is single-threaded; bench.py's "all cores" column raises it explicitly
     return _lib
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    """OpenMP threads of the dense factorisation (results do not depend on it)."""
+    lib().ora_set_threads(int(n))
 
 
 class Problem:
