@@ -57,6 +57,19 @@ def algorithmic_bytes(N, M, K, S=8):
     return b_evalRJ, b_evalR, b_schur
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box hands a
+    16-core share of a 256-thread host to each GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("BA_CPU_BASELINE_CORES", "16")))
+
+
 def cpu_baseline(name, prob, budget_s=20.0):
     """The CPU oracle timed on a bounded sample of the same workload: ONE thread like the reference (no OpenMP / TBB in its build,
     clock() timing), and -- labelled as not the reference -- the same port with OpenMP on all host cores."""
@@ -87,8 +100,8 @@ def cpu_baseline(name, prob, budget_s=20.0):
 
     ntr, el = timed(1, budget_s)
     out = {"value": ntr / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-           "sample": "first %d LM trials of the same workload by oracle/ba_oracle.c (gcc -O2, 1 thread, blocked dense LDL^T), %.1f s" % (ntr, el)}
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+           "sample": "first %d LM trials of the same workload by oracle/ba_oracle.c (gcc -O3, 1 thread, blocked dense LDL^T), %.1f s" % (ntr, el)}
+    ncores = host_cores()
     if ncores > 1:
         ntr2, el2 = timed(ncores, budget_s / 2)
         out["all_cores"] = {"value": ntr2 / el2, "cores": ncores, "note": "the same port with OpenMP on every host core -- NOT the reference "

@@ -581,7 +581,7 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipGetLastError());
         tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
         tm.schur_ms += ev_ms(EV_T1, EV_T2);
-        tm.comm_ms += ev_ms(EV_T2, EV_T3);
+        if (sharded()) tm.comm_ms += ev_ms(EV_T2, EV_T3);
         tm.factor_ms += ev_ms(EV_T3, EV_T4);
         tm.backsub_ms += ev_ms(EV_T4, EV_T5);
         tm.test_eval_ms += ev_ms(EV_T5, EV_T6);
@@ -790,7 +790,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         EvSlot &e = ring[slot];
         tm.trial_ms += ev_ms(e.e[0], e.e[4]);
-        tm.comm_ms += ev_ms(e.e[1], e.e[2]) + ev_ms(e.e[3], e.e[4]);
+        if (sharded()) tm.comm_ms += ev_ms(e.e[1], e.e[2]) + ev_ms(e.e[3], e.e[4]);
         tm.n_trials++;
         tm.n_graph_trials++;
         if (accepted) { tm.linearize_ms += ev_ms(e.e[4], e.e[5]); tm.n_linearize++; }
