@@ -84,8 +84,7 @@ def cpu_baseline(name, prob, budget_s=20.0):
     a = prob.arrays()
     po = O.Problem(prob.N, prob.M, prob.K, a["cam_idx"], a["pt_idx"], a["meas"], a["cams9"], a["pts"])
     dt = np.float64 if scalar == "f64" else np.float32
-    # QRKIT: the oracle's dense thin QR of the right block is O(K D^2) -- timed through the QRCHOL loop it shares everything else with
-    okind = {"QRKIT": O.QRCHOL, "QRCHOL": O.QRCHOL, "CHOLESKY": O.CHOLESKY}[kind]
+    okind = {"QRKIT": O.QRKIT, "QRCHOL": O.QRCHOL, "CHOLESKY": O.CHOLESKY}[kind]
 
     def timed(threads, budget):
         O.set_threads(threads)
@@ -180,7 +179,7 @@ def main():
         D = 9 * N
         b_evalRJ, b_evalR, b_schur = algorithmic_bytes(N, M, K, S)
         ntr = max(tm["n_trials"], 1)
-        label = kind_s + (" symbol (runs the QRCHOL loop: per-point QR + LDL^T of the reduced system, DESIGN.md section 2)" if kind_s == "QRKIT" else " solver")
+        label = kind_s + (" solver (per-point QR + dense Householder QR of J2bot; sharded runs fall back to LDL^T of the all-reduced S)" if kind_s == "QRKIT" else " solver")
         out = {
             "metric": "LM iterations/sec", "value": steps_done / el, "unit": "LM iterations/s", "n_gpus": world,
             "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps_done, 1),

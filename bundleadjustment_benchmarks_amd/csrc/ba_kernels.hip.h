@@ -412,7 +412,9 @@ template <typename T, int LPP, int SL> // SL observations per lane: points with 
 __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict__ pt_list, int Ml, int K, const int *__restrict__ pt_ptr,
                                                  const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ r,
                                                  const T *__restrict__ lam, T *__restrict__ rec, T *__restrict__ dinv,
-                                                 T *__restrict__ tvec, T *__restrict__ tri, const int *__restrict__ go = nullptr)
+                                                 T *__restrict__ tvec, T *__restrict__ tri, const int *__restrict__ go = nullptr,
+                                                 T *__restrict__ q1obs = nullptr /* [K][6]: thin Q rows per observation (QRKIT) */,
+                                                 T *__restrict__ q1lam = nullptr /* [Ml][9]: thin Q rows of the lambda rows */)
 {
     if (go && *go == 0) return; // (MOREQR's outer factorisation is part of the conditional linearisation)
     // the points of one track-length bucket (pt_list; the host buckets them so that a short track does not occupy the lanes
@@ -493,6 +495,20 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
         for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = q1[c]; }
         tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
         tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
+        if (q1lam) {
+#pragma unroll
+            for (int h = 0; h < 3; h++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) q1lam[9 * (size_t)j + 3 * h + c] = Ql[h][c];
+        }
+    }
+    if (q1obs && gid < npts) {
+#pragma unroll
+        for (int s = 0; s < SL; s++)
+            if (ok[s]) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) q1obs[6 * (size_t)(b + s * LPP + lg) + q] = Q[s][q];
+            }
     }
     // Z_i = A_i^T Q1_i (9x3)
     if (gid < npts) {

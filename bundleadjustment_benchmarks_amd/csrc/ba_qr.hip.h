@@ -1,0 +1,261 @@
+// ba_qr.hip.h -- the QRKIT symbol's right block: dense thin Householder QR of J2bot (src/Optimization/BAFunctor.h:99-102:
+// BlockAngularSparseQR< J, BlockDiagonalSparseQR<ColPivHouseholderQR>, DenseBlockedThinQR<MatrixXX, NaturalOrdering, 4, true> >;
+// README.md:14 "block diagonal QR on the left block, dense QR on the lower-right block").  QRKit itself is not vendored; what is
+// restated is what that type says: after the per-point QR of the left block (k_elim_qr) the rows of Q^T [J_c ; 0] below each
+// point's top three -- J2bot, (2K + 3M + D) x D with the camera sqrt(lambda) rows, dense storage -- are factored by Householder
+// reflections and the camera step solves  min || J2bot y + qtb2 ||  through R y = -Q^T qtb2.  No normal equations: this is the
+// one symbol whose reduced system is never squared (cond(J2bot) = sqrt(cond(S))), which is what it is there for in fp32.
+//
+// J2bot is built as (I - Q1 Q1^T) [A ; 0] per point -- all 2 k_j + 3 rows, i.e. the rows orthogonal to the point's thin Q1 up to
+// an orthogonal row transform, which leaves R and the least-squares solution unchanged (the CPU oracle does the same,
+// oracle/ba_oracle_impl.h: solve_reduced_qr).
+//
+// The QR is blocked by 32-column panels; a panel is factored as a TSQR tree so that no reflector ever needs a grid-wide
+// reduction: level 1 cuts the rows into chunks of CH (1024 fp32 / 512 fp64) that one workgroup factors in LDS (Householder,
+// column by column, reflectors stored in place below the diagonal of the chunk, the chunk's 32 x 32 R on its top rows); level
+// L + 1 stacks the R's of NSB = CH / 32 level-L chunks (their top rows, in place: row stride CH * NSB^(L-1)) and factors the
+// stack the same way -- its reflectors only have entries where the stacked triangles had them, so they fit in the triangles
+// they annihilate and the lower-level reflectors underneath stay intact.  The trailing columns (and the right-hand side, which
+// rides along as column D) receive the chunk reflectors level by level: one workgroup per (chunk, 32 columns) holds the tile in
+// LDS and applies the 32 reflectors one after the other (fp32 matrix cores run at the vector rate on this chip, and the
+// tile never leaves LDS, so the compact-WY form would buy nothing here).
+#ifndef BA_QR_HIP_H
+#define BA_QR_HIP_H
+
+#include <hip/hip_runtime.h>
+
+#define BA_QR_PB 32 /* panel width = rows of a sub-block */
+
+template <typename T> struct ba_qr_cfg {
+    static constexpr int NSB = sizeof(T) == 4 ? 32 : 16; // sub-blocks (of 32 rows) per chunk
+    static constexpr int CH = BA_QR_PB * NSB;            // rows per chunk: 128 KiB of LDS for a CH x 32 tile
+};
+
+// global row of local row l of chunk g: sub-block s = l / 32 starts at row0 + (g NSB + s) stride, stride = 32 at level 1
+template <typename T> __device__ __forceinline__ size_t ba_qr_row(int row0, int g, int l, long long stride)
+{
+    return (size_t)row0 + (size_t)((long long)g * ba_qr_cfg<T>::NSB + (l >> 5)) * (size_t)stride + (size_t)(l & 31);
+}
+
+// ---- J2bot ------------------------------------------------------------------------------------------------------------
+// One thread per observation ia (point j, camera a): the 9 columns of camera a in all rows of point j:
+//   observation rows of ib:  delta(ia, ib) A_ib - Q1_ib Z_ia^T   (2 x 9)      Z_ia = R12_ia^T = A_ia^T Q1_ia (rec)
+//   lambda rows of j:        - Q1lam_j Z_ia^T                    (3 x 9)
+// and, by the first observation of the point, the right-hand side column D:  -(r_ib - Q1_ib q1) and +Q1lam q1  (q1 = -tvec).
+// Row layout: point j with observations [b, e) owns rows 2 b + 3 j ... ; the camera sqrt(lambda) rows follow at 2 K + 3 M.
+template <typename T>
+__global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                                     const int *__restrict__ pt_ptr, const T *__restrict__ Jc /* SoA [18][K] */,
+                                                     const T *__restrict__ r /* SoA [2][K] */, const T *__restrict__ rec,
+                                                     const T *__restrict__ q1obs /* [K][6] */, const T *__restrict__ q1lam /* [Ml][9] */,
+                                                     const T *__restrict__ tvec /* SoA [3][Ml] = -q1 */, const T *__restrict__ lam,
+                                                     T *__restrict__ A, size_t lda)
+{
+    const int ia = blockIdx.x * 256 + threadIdx.x;
+    if (ia < D) A[(size_t)ia * lda + 2 * (size_t)K + 3 * (size_t)Ml + ia] = sqrt(*lam); // camera rows: sqrt(lambda) I_D, zero rhs
+    if (ia >= K) return;
+    const int j = obs_pt[ia], a = obs_cam[ia], b = pt_ptr[j], e = pt_ptr[j + 1];
+    const size_t r0 = 2 * (size_t)b + 3 * (size_t)j;
+    T Z[27];
+#pragma unroll
+    for (int q = 0; q < 27; q++) Z[q] = rec[(size_t)ia * BA_REC + q];
+    T *colbase = A + (size_t)(9 * a) * lda;
+    for (int ib = b; ib < e; ib++) {
+        const T *Q = q1obs + 6 * (size_t)ib; // 2 x 3 row-major
+        T q[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) q[m] = Q[m];
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                T v = (ib == ia) ? Jc[(size_t)(9 * rr + c) * K + ia] : (T)0;
+                v -= q[3 * rr] * Z[3 * c] + q[3 * rr + 1] * Z[3 * c + 1] + q[3 * rr + 2] * Z[3 * c + 2];
+                colbase[(size_t)c * lda + r0 + 2 * (size_t)(ib - b) + rr] = v;
+            }
+    }
+    const T *Ql = q1lam + 9 * (size_t)j; // 3 x 3 row-major: lambda row rr, column m
+    const size_t rl = r0 + 2 * (size_t)(e - b);
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            colbase[(size_t)c * lda + rl + rr] = -(Ql[3 * rr] * Z[3 * c] + Ql[3 * rr + 1] * Z[3 * c + 1] + Ql[3 * rr + 2] * Z[3 * c + 2]);
+    if (ia == b) { // right-hand side of the point: -(qtb2) = -( [r ; 0] - Q1 q1 ),  q1 = -t
+        const T t0 = -tvec[j], t1 = -tvec[(size_t)Ml + j], t2 = -tvec[2 * (size_t)Ml + j];
+        T *rhs = A + (size_t)D * lda;
+        for (int ib = b; ib < e; ib++) {
+            const T *Q = q1obs + 6 * (size_t)ib;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+                rhs[r0 + 2 * (size_t)(ib - b) + rr] = -(r[(size_t)rr * K + ib] - (Q[3 * rr] * t0 + Q[3 * rr + 1] * t1 + Q[3 * rr + 2] * t2));
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) rhs[rl + rr] = Ql[3 * rr] * t0 + Ql[3 * rr + 1] * t1 + Ql[3 * rr + 2] * t2;
+    }
+}
+
+// ---- one chunk of a TSQR level: Householder QR of its rows of the panel, in LDS -----------------------------------------
+// level 1: the chunk's rows are dense; level > 1: every sub-block is an upper triangle (the R of a lower-level chunk) -- entries
+// below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
+                                                  T *__restrict__ tau /* [chunks][32] */)
+{
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH;
+    __shared__ T Ac[BA_QR_PB][CH + 1];
+    __shared__ T red[8][BA_QR_PB + 1];
+    __shared__ T sc_s[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
+    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
+        const int c = idx / CH, l = idx - c * CH;
+        T v = 0;
+        if (c < bw && l < rows && (level == 1 || (l & 31) <= c)) v = A[(size_t)(c0 + c) * lda + ba_qr_row<T>(row0, g, l, stride)];
+        Ac[c][l] = v;
+    }
+    __syncthreads();
+    const int cc = tid & 31, rg = tid >> 5; // column / row group of this thread in the update phase
+    for (int j = 0; j < bw; j++) {
+        // |x|^2 below the pivot
+        T xn = 0;
+        for (int l = j + 1 + tid; l < rows; l += 256) xn += Ac[j][l] * Ac[j][l];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) xn += __shfl_down(xn, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][0] = xn;
+        __syncthreads();
+        if (tid == 0) {
+            const T x2 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            const T alpha = Ac[j][j];
+            T tj = 0, sc = 0, beta = alpha;
+            if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
+                beta = sqrt(alpha * alpha + x2);
+                if (alpha > (T)0) beta = -beta;
+                tj = (beta - alpha) / beta;
+                sc = (T)1.0 / (alpha - beta);
+            }
+            sc_s[0] = tj; sc_s[1] = sc; sc_s[2] = beta;
+            tau[(size_t)g * BA_QR_PB + j] = tj;
+        }
+        __syncthreads();
+        const T tj = sc_s[0], sc = sc_s[1];
+        for (int l = j + 1 + tid; l < rows; l += 256) Ac[j][l] *= sc;
+        if (tid == 0) Ac[j][j] = sc_s[2];
+        __syncthreads();
+        // w_c = tau (a_c[j] + v . a_c) for the columns behind j, then a_c -= v w_c
+        T dot = 0;
+        if (cc > j && cc < bw)
+            for (int l = j + 1 + rg; l < rows; l += 8) dot += Ac[j][l] * Ac[cc][l];
+        red[rg][cc] = dot;
+        __syncthreads();
+        if (cc > j && cc < bw) {
+            T d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) d += red[q][cc];
+            const T w = tj * (Ac[cc][j] + d);
+            for (int l = j + 1 + rg; l < rows; l += 8) Ac[cc][l] -= Ac[j][l] * w;
+            if (rg == 0) Ac[cc][j] -= w;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
+        const int c = idx / CH, l = idx - c * CH;
+        if (c < bw && l < rows && (level == 1 || (l & 31) <= c)) A[(size_t)(c0 + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = Ac[c][l];
+    }
+}
+
+// ---- the reflectors of one chunk applied to 32 trailing columns ----------------------------------------------------------
+// grid (chunks, column tiles); the tile (chunk rows x 32 columns) lives in LDS while the 32 reflectors pass over it.
+// Reflector j of the chunk: 1 at local row j, zero above; below: level 1 -- the stored panel column; level > 1 -- in every
+// sub-block behind the first only the rows t <= j (the triangle it annihilated).
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
+                                                  const T *__restrict__ tau, int col0, int col1)
+{
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH;
+    __shared__ T B[BA_QR_PB][CH + 1];
+    __shared__ T vs[CH];
+    __shared__ T red[8][BA_QR_PB + 1];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int cb = col0 + BA_QR_PB * blockIdx.y, ncol = min(BA_QR_PB, col1 - cb);
+    const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
+    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
+        const int c = idx / CH, l = idx - c * CH;
+        B[c][l] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] : (T)0;
+    }
+    const int cc = tid & 31, rg = tid >> 5;
+    for (int j = 0; j < bw; j++) {
+        const T tj = tau[(size_t)g * BA_QR_PB + j];
+        __syncthreads(); // (the previous reflector's reads of vs, and the fill of B on the first pass)
+        for (int l = tid; l < rows; l += 256) {
+            T v = 0;
+            if (l == j) v = 1;
+            else if (l > j && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j))) v = A[(size_t)(c0 + j) * lda + ba_qr_row<T>(row0, g, l, stride)];
+            vs[l] = v;
+        }
+        __syncthreads();
+        T dot = 0;
+        for (int l = j + rg; l < rows; l += 8) dot += vs[l] * B[cc][l];
+        red[rg][cc] = dot;
+        __syncthreads();
+        T d = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) d += red[q][cc];
+        const T w = tj * d;
+        for (int l = j + rg; l < rows; l += 8) B[cc][l] -= vs[l] * w;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
+        const int c = idx / CH, l = idx - c * CH;
+        if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = B[c][l];
+    }
+}
+
+// ---- R y = (Q^T rhs)[0 : D): back substitution by one workgroup ------------------------------------------------------------
+// R is the upper triangle of the first D rows of A, the transformed right-hand side column D.  Column-oriented: y_j =
+// b_j / R_jj, then b_i -= R_ij y_j for i < j (the column of R is contiguous in memory).
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, size_t lda, int D, T *__restrict__ y)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T *b = reinterpret_cast<T *>(smem_raw);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < D; i += 256) b[i] = A[(size_t)D * lda + i];
+    __syncthreads();
+    for (int j = D - 1; j >= 0; j--) {
+        const T *col = A + (size_t)j * lda;
+        const T yj = b[j] / col[j];
+        __syncthreads();
+        if (tid == 0) { b[j] = yj; y[j] = yj; }
+        for (int i = tid; i < j; i += 256) b[i] -= col[i] * yj;
+        __syncthreads();
+    }
+}
+
+// Host side: QR of the (mrows x D) matrix A (+ rhs in column D) on `st`, then y = argmin || A y - rhs ||.
+// A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: room for (ceil(mrows / CH) + 2) * 32 scalars per level, 4 levels.
+template <typename T>
+inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y)
+{
+    constexpr int NSB = ba_qr_cfg<T>::NSB;
+    for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
+        const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
+        const int col0 = c0 + bw, col1 = D + 1; // trailing columns incl. the right-hand side
+        int nsb = (mrows - c0 + BA_QR_PB - 1) / BA_QR_PB; // 32-row blocks from the panel's first row down
+        long long stride = BA_QR_PB;
+        for (int level = 1;; level++) {
+            const int nch = (nsb + NSB - 1) / NSB;
+            T *tl = tau + (size_t)(level - 1) * tau_level_stride;
+            hipLaunchKernelGGL((k_qr_chunk<T>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl);
+            const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB;
+            if (nct > 0)
+                hipLaunchKernelGGL((k_qr_apply<T>), dim3(nch, nct), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1);
+            if (nch == 1) break;
+            nsb = nch;
+            stride *= NSB;
+        }
+    }
+    hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)D, st, (const T *)A, lda, D, y);
+}
+
+#endif

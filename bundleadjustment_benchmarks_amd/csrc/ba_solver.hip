@@ -9,6 +9,7 @@
 #include "ba_internal.h"
 #include "ba_kernels.hip.h"
 #include "ba_dense.hip.h"
+#include "ba_qr.hip.h"
 
 #include <chrono>
 #include <cmath>
@@ -126,6 +127,11 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     DevBuf<ba_lm_dev<T>> d_lm; // LM state of the device-side step control (k_lm_control)
+    // QRKIT (single shard): dense J2bot (+ rhs column) for the Householder QR of the right block, its reflector scalars, the thin Q rows
+    DevBuf<T> d_qA, d_qtau, d_q1obs, d_q1lam;
+    size_t q_lda = 0, q_tau_stride = 0;
+    int q_rows = 0;
+    bool dense_qr() const { return kind == BA_QRKIT && !sharded(); }
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
     T *h_lam = nullptr; // pinned staging word for lambda
@@ -292,6 +298,17 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_V, (size_t)81 * N); AL(d_gc, (size_t)D);
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
+        if (kind == BA_QRKIT && world == 1) {
+            // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
+            for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
+                for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
+                    for (int i2 = sx.pt_ptr[j]; i2 < i; i2++)
+                        if (sx.obs_cam[i] == sx.obs_cam[i2]) return BA_ERR_ARG;
+            q_rows = 2 * Kl + 3 * Ml + D;
+            q_lda = (size_t)q_rows + 64;
+            q_tau_stride = (size_t)((q_rows + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB;
+            AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, 8 * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
+        }
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
@@ -433,18 +450,19 @@ template <typename T> struct Solver final : SolverBase {
                 hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
                                    d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
         } else {
-            launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p, nullptr);
+            launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p, nullptr, dense_qr());
         }
     }
 
     // per-point QR, one launch per non-empty track-length bucket (ba_structure: lanes per point x observations per lane)
-    void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri, const int *go)
+    void launch_elim_qr(const T *lam, T *rec, T *dinv, T *tvec, T *tri, const int *go, bool thin_q = false)
     {
+        T *qo = thin_q ? d_q1obs.p : nullptr, *ql = thin_q ? d_q1lam.p : nullptr;
 #define BA_QR(B, L, SLOTS)                                                                                                       \
         if (sx.qr_bucket_ptr[B + 1] > sx.qr_bucket_ptr[B]) {                                                                   \
             const int np_ = sx.qr_bucket_ptr[B + 1] - sx.qr_bucket_ptr[B];                                                       \
             hipLaunchKernelGGL((k_elim_qr<T, L, SLOTS>), dim3(((size_t)np_ * L + 255) / 256), dim3(256), 0, st, np_,           \
-                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri, go); \
+                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri, go, qo, ql); \
         }
         BA_QR(0, 8, 4)
         BA_QR(1, 16, 4)
@@ -472,6 +490,20 @@ template <typename T> struct Solver final : SolverBase {
     }
 
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
+
+    // QRKIT's right block (BAFunctor.h:101): J2bot built densely, Householder QR (ba_qr.hip.h), dx_c from R y = -Q^T qtb2
+    void launch_qrkit_build()
+    {
+        (void)hipMemsetAsync(d_qA.p, 0, sizeof(T) * d_qA.n, st);
+        const int nthr = std::max(Kl, D);
+        hipLaunchKernelGGL((k_qrkit_build<T>), dim3((nthr + 255) / 256), dim3(256), 0, st, Kl, Ml, D, d_obs_cam.p, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_r.p,
+                           d_rec.p, d_q1obs.p, d_q1lam.p, d_tvec.p, d_scal.p + SC_LAMBDA, d_qA.p, q_lda);
+    }
+    void launch_qrkit_solve()
+    {
+        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p);
+        (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
+    }
 
     void launch_factor() { ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR); }
 
@@ -528,13 +560,19 @@ template <typename T> struct Solver final : SolverBase {
 
     // The segments of one trial (everything behind lambda in SC_LAMBDA).  Single shard: A + B back to back; sharded: an
     // all-reduce of the packed system between A and B and one of the three step scalars behind B.
-    int launch_seg_a() { launch_eliminate(); launch_schur(); return sharded() ? launch_pack(false) : BA_OK; }
+    int launch_seg_a()
+    {
+        launch_eliminate();
+        if (dense_qr()) { launch_qrkit_build(); return BA_OK; }
+        launch_schur();
+        return sharded() ? launch_pack(false) : BA_OK;
+    }
     int launch_seg_b()
     {
         int rc;
         if (sharded() && (rc = launch_pack(true))) return rc;
-        launch_post_reduce();
-        launch_factor_solve();
+        if (dense_qr()) launch_qrkit_solve();
+        else { launch_post_reduce(); launch_factor_solve(); }
         launch_backsub_retract();
         launch_test_energy();
         return BA_OK;
@@ -559,18 +597,21 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T0], st));
         launch_eliminate();
         HIPCHK(hipEventRecord(ev[EV_T1], st));
-        launch_schur();
+        if (dense_qr()) launch_qrkit_build(); else launch_schur();
         HIPCHK(hipEventRecord(ev[EV_T2], st));
         if (sharded()) {
             if ((rc = launch_pack(false)) || (rc = allreduce(d_pack.p, pack_count() + 1, 0)) || (rc = launch_pack(true))) return rc;
         }
         HIPCHK(hipEventRecord(ev[EV_T3], st));
-        launch_post_reduce();
-        if (keep) {
-            if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
-            HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
+        if (dense_qr()) launch_qrkit_solve();
+        else {
+            launch_post_reduce();
+            if (keep) {
+                if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
+                HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
+            }
+            launch_factor_solve();
         }
-        launch_factor_solve();
         HIPCHK(hipEventRecord(ev[EV_T4], st));
         launch_backsub_retract();
         HIPCHK(hipEventRecord(ev[EV_T5], st));
@@ -933,15 +974,25 @@ template <typename T> struct Solver final : SolverBase {
             case 0: launch_eval(false, 0); break;
             case 1: launch_eval(true, 0); launch_grad(); break;
             case 2: launch_eliminate(); break;
-            case 3: launch_schur(); break;
+            case 3: if (dense_qr()) launch_qrkit_build(); else launch_schur(); break; // (QRKIT: J2bot instead of S)
             case 4:
+                if (dense_qr()) { launch_qrkit_build(); launch_qrkit_solve(); break; }
                 launch_schur(); // the factorisation is in place: rebuild S first (timed separately by phase 3)
                 launch_post_reduce();
                 launch_factor_solve();
                 break;
             case 5: launch_backsub_retract(); break;
-            case 6: // dense factorisation only (k_ldlt_panel + k_ldlt_step / k_ldlt_update): events around it, per rep
-            case 7: // backward sweep only (k_ldlt_backstep)
+            case 6: // dense factorisation only (k_ldlt_panel + k_ldlt_step / k_ldlt_update; QRKIT: the Householder QR + solve): events around it, per rep
+            case 7: // backward sweep only (k_ldlt_backflow; QRKIT: nothing, the solve is part of 6)
+                if (dense_qr()) {
+                    launch_qrkit_build();
+                    HIPCHK(hipEventRecord(ev[EV_T2], st));
+                    if (phase == 6) launch_qrkit_solve();
+                    HIPCHK(hipEventRecord(ev[EV_T3], st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    acc_ms += ev_ms(EV_T2, EV_T3);
+                    break;
+                }
                 launch_schur();
                 launch_post_reduce();
                 if (phase == 6) HIPCHK(hipEventRecord(ev[EV_T2], st));

@@ -40,6 +40,33 @@ for name in cfgs:
         e_fin = tr[-1, 6] if tr[-1, 1] == 1 else tr[-1, 2]
         n = min(len(tr), len(r["trace"]))
         same = np.where(tr[:n, 1] != r["trace"][:n, 1])[0]
+        dto = np.float64 if scalar_s == "f64" else np.float32
+        so0 = O.stats(po, O.init_cams(po, dto), po.pts.astype(dto))
+        so1 = O.stats(po, ro["cam15"], ro["pts"])
+        row.update({"cpu_mean_err_before": so0["mean_err"], "cpu_mean_err_after": so1["mean_err"], "cpu_inliers_after": so1["n_inliers"],
+                    "cpu_objective_after": so1["objective"], "gpu_objective_after": st1["objective"]})
+        if not np.isfinite(st1["mean_err"]) or not np.isfinite(so1["mean_err"]):
+            # which observation goes non-finite, on which side, and why (fp64 re-evaluation of the final parameters)
+            def worst(cam15, pts, tag):
+                c = np.asarray(cam15, np.float64).reshape(-1, 15)
+                X = np.asarray(pts, np.float64).reshape(-1, 3)
+                ci, pi = po.cam_idx, po.pt_idx
+                R = c[ci, :9].reshape(-1, 3, 3)
+                XX = np.einsum("kij,kj->ki", R, X[pi]) + c[ci, 9:12]
+                xu = XX[:, :2] / XX[:, 2:3]
+                r2 = (xu ** 2).sum(1)
+                kr = 1 + c[ci, 13] * r2 + c[ci, 14] * r2 * r2
+                q = c[ci, 12:13] * kr[:, None] * xu
+                err = np.linalg.norm(q - po.meas.reshape(-1, 2), axis=1)
+                with np.errstate(over="ignore", invalid="ignore"):
+                    r2f = r2.astype(np.float32)
+                    ovf = ~np.isfinite((r2f * r2f * c[ci, 14].astype(np.float32)))
+                k = int(np.nanargmax(np.where(np.isfinite(err), err, np.inf)))
+                return {tag + "_worst_obs": k, tag + "_worst_err_fp64": float(err[k]), tag + "_worst_depth_XX2": float(XX[k, 2]),
+                        tag + "_worst_r2u": float(r2[k]), tag + "_nonfinite_in_fp64": int((~np.isfinite(err)).sum()),
+                        tag + "_float_overflow_of_k2_r4": int(ovf.sum()), tag + "_n_err_gt_1e6": int((err > 1e6).sum())}
+            row.update(worst(s.get(ba.GET_CAMS), s.get(ba.GET_POINTS), "gpu"))
+            row.update(worst(ro["cam15"], ro["pts"], "cpu"))
         row.update({"cpu_status": ba.STATUS[ro["status"]], "cpu_trials": len(tr), "cpu_seconds": elo, "cpu_trials_per_s": len(tr) / elo,
                     "cpu_final_energy": float(e_fin), "rel_final_energy_diff": abs(float(e_fin) - r["energy"]) / float(e_fin),
                     "first_accept_reject_difference_at_trial": int(same[0]) + 1 if len(same) else None})

@@ -184,11 +184,12 @@ def test_cfg5_full_size(ba, O, gpu_ok):
 
 @pytest.mark.parametrize("kind", [0, 1])
 def test_cfg3_f32_lm(ba, O, gpu_ok, prob39, kind):
-    """Scalar = float on problem-39 under the QRKIT symbol (config 3) and under QRCHOL: the accepted energies decrease, the
-    first trial agrees with the fp32 oracle of the same symbol (energy before 1e-5, test energy 2e-3, accept decision), and the
+    """Scalar = float on problem-39 under the QRKIT symbol (config 3: per-point QR + dense Householder QR of J2bot, 181 k x 351)
+    and under QRCHOL: the accepted energies decrease, the first trial agrees with the fp32 oracle of the same symbol (energy
+    before 1e-5, test energy 2e-3, accept decision; the oracle's dense QR of that matrix takes ~1/2 minute per trial), and the
     statistics after the run are finite."""
     po = to_oracle(prob39)
-    ro = O.minimize(kind, po, dtype=np.float32, max_trials=3)["trace"]
+    ro = O.minimize(kind, po, dtype=np.float32, max_trials=2)["trace"]
     s = ba.Solver(prob39, kind, ba.F32)
     r = s.minimize(max_trials=15)
     tg = r["trace"]

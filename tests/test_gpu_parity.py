@@ -166,9 +166,10 @@ def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
 
 @pytest.mark.parametrize("kind", [2, 1, 0, 3])
 def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
-    """Scalar = float (src/BATypeUtils.h:6-7): one trial against the float oracle with the same elimination order.
+    """Scalar = float (src/BATypeUtils.h:6-7): one trial against the float oracle of the same symbol.
     fp32 leaves ~1e-3 on S (entries up to 1e9 accumulated from ~1e3 terms) and, through cond(S), a few percent on dx;
-    the energy of the trial point must agree to 1e-3."""
+    the energy of the trial point must agree to 1e-3.  QRKIT (kind 0) never forms S: its right block is the dense Householder QR
+    of J2bot on both sides (ba_qr.hip.h / oracle solve_reduced_qr)."""
     po = to_oracle(small)
     cam = O.init_cams(po, np.float32)
     pts = po.pts.astype(np.float32)
@@ -178,16 +179,59 @@ def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
     s.keep_intermediates(True)
     eg, dmax = s.linearize()
     assert abs(eg - e) < 1e-4 * e
-    okind = O.QRCHOL if kind == 0 else kind  # QRKIT on the GPU = per-point QR + LDL^T of S
     for lam in (1.0, 100.0):
-        st = O.step(okind, po, Jc, Jp, f, lam)
+        st = O.step(kind, po, Jc, Jp, f, lam)
         et, rs, dn = s.try_step(lam)
-        assert relmax(s.get(ba.GET_S), st["S"]) < 5e-3
+        if kind != 0:
+            assert relmax(s.get(ba.GET_S), st["S"]) < 5e-3
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 5e-2 * np.linalg.norm(st["dx"])
         co, pt = O.retract(po, cam, pts, st["dx"])
         _, e_or = O.residuals(po, co, pt)
         assert abs(et - e_or) < 1e-3 * e_or
+
+
+@pytest.mark.parametrize("src", ["small", "p21sub"])
+def test_qrkit_dense_qr_step_f64(ba, O, gpu_ok, small, prob21, src):
+    """QRKIT in fp64: the dense Householder QR of J2bot (TSQR panels, ba_qr.hip.h) against the oracle's dense QR of the same
+    matrix (solve_reduced_qr) and against the QRCHOL step, which solves the same least-squares problem through S: the step to
+    1e-7 / 1e-6, the backward error of the whole step in the normal equations to 1e-10 (a QR does better than LDL^T of S there).
+    `p21sub`: the first 1500 points of problem-21 (D = 189: six panels, the last one 29 wide; 14 k rows: three TSQR levels)."""
+    if src == "small":
+        pg, po = small, to_oracle(small)
+    else:
+        a = prob21.arrays()
+        npts = 1500
+        k = int(np.searchsorted(a["pt_idx"], npts, side="left"))
+        pg = ba.Problem.from_arrays(prob21.N, npts, k, a["cam_idx"][:k], a["pt_idx"][:k], a["meas"][:2 * k], a["cams9"], a["pts"][:3 * npts])
+        po = to_oracle(pg)
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(pg, ba.QRKIT, ba.F64)
+    eg, dmax = s.linearize()
+    assert abs(eg - e) < 1e-12 * e
+    for lam in (1e-12 * dmax, 1e-3, 10.0):
+        st = O.step(O.QRKIT, po, Jc, Jp, f, lam, want_S=False)
+        sc = O.step(O.QRCHOL, po, Jc, Jp, f, lam, want_S=False)
+        et, rs, dn = s.try_step(lam)
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
+        assert np.linalg.norm(dx - sc["dx"]) < 1e-6 * np.linalg.norm(sc["dx"])
+        M, N = po.M, po.N
+        Jdx = np.einsum("krc,kc->kr", Jc, dx[3 * M:].reshape(N, 9)[po.cam_idx]) + np.einsum("krc,kc->kr", Jp, dx[:3 * M].reshape(M, 3)[po.pt_idx])
+        res = np.zeros_like(dx)
+        np.add.at(res[3 * M:].reshape(N, 9), po.cam_idx, np.einsum("krc,kr->kc", Jc, Jdx))
+        np.add.at(res[:3 * M].reshape(M, 3), po.pt_idx, np.einsum("krc,kr->kc", Jp, Jdx))
+        assert np.linalg.norm(res + lam * dx - st["g"]) < 1e-10 * np.linalg.norm(st["g"])
+        co, pt = O.retract(po, cam, po.pts, st["dx"])
+        _, e_or = O.residuals(po, co, pt)
+        assert abs(et - e_or) < 1e-7 * e_or
+        assert abs(rs - float(st["dx"] @ (lam * st["dx"] + st["g"]))) < 1e-6 * abs(rs)
+    # the production loop on the symbol: same accept / reject and energies as the oracle's QRKIT loop
+    ro = O.minimize(O.QRKIT, po, max_trials=6)["trace"]
+    rg = ba.Solver(pg, ba.QRKIT, ba.F64).minimize(max_trials=6)["trace"]
+    assert np.array_equal(rg[:, :2], ro[:, :2]) and np.allclose(rg[:3, 2], ro[:3, 2], rtol=1e-7) and np.allclose(rg[:, 2], ro[:, 2], rtol=1e-4)
 
 
 def test_f32_lm_decreases(ba, gpu_ok, prob39):
