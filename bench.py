@@ -213,7 +213,18 @@ def main():
         secondary = {"bound": "hbm", "kernel": "k_elim_* + k_schur_pairs + k_schur_reduce + k_backsub", "achieved": by_hbm / (t_hbm * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm,
                      "traffic": None}
-        if ph["dense_factor"] >= t_hbm:
+        if kind_s == "QRKIT":
+            # the right block of this symbol is the dense Householder QR of J2bot, (2K + 3M + D) x D: 2 m D^2 flops on the vector /
+            # matrix units (fp32: the same rate), one k_qr_apply launch per (panel, TSQR level)
+            mrows = 2 * K + 3 * M + D
+            flops_qr = 2.0 * mrows * D * D
+            peak = FP64_PEAK_TF if S == 8 else FP32_PEAK_TF
+            ach = flops_qr / (ph["dense_factor"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_qr_chunk + k_qr_apply<%s> (blocked Householder QR of the dense %dx%d J2bot, TSQR panels; "
+                               "peak = the fp%d matrix/vector rate)" % ("double" if S == 8 else "float", mrows, D, 8 * S),
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "algorithmic_flops_per_trial": flops_qr, "ms_per_trial": ph["dense_factor"], "secondary": secondary}
+        elif ph["dense_factor"] >= t_hbm:
             # k_ldlt_step (fused panel + trailing update; k_ldlt_panel for the first block column): nblk launches per trial,
             # each processing 1/nblk of the D^3/3 flops on average
             peak = FP64_PEAK_TF if S == 8 else FP32_PEAK_TF
