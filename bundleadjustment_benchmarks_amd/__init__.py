@@ -12,9 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libba_mi355x.so")
 
-QRKIT, QRCHOL, CHOLESKY, MOREQR = 0, 1, 2, 3
+QRKIT, QRCHOL, CHOLESKY, MOREQR, QRSPQR = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
-KIND_NAMES = {QRKIT: "QRKIT", QRCHOL: "QRCHOL", CHOLESKY: "CHOLESKY", MOREQR: "MOREQR"}
+KIND_NAMES = {QRKIT: "QRKIT", QRCHOL: "QRCHOL", CHOLESKY: "CHOLESKY", MOREQR: "MOREQR", QRSPQR: "QRSPQR"}
 STATUS = {-2: "NotStarted", -1: "Running", 0: "Success", 1: "ExceededLambdaMax", 2: "TooManyFunctionEvaluation",
           3: "MaxItersReached"}
 

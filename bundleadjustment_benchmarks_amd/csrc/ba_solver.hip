@@ -131,7 +131,7 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<T> d_qA, d_qtau, d_q1obs, d_q1lam;
     size_t q_lda = 0, q_tau_stride = 0;
     int q_rows = 0;
-    bool dense_qr() const { return kind == BA_QRKIT && !sharded(); }
+    bool dense_qr() const { return (kind == BA_QRKIT || kind == BA_QRSPQR) && !sharded(); } // (QRSPQR: see include/ba_mi355x.h)
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
     T *h_lam = nullptr; // pinned staging word for lambda
@@ -298,7 +298,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_V, (size_t)81 * N); AL(d_gc, (size_t)D);
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
-        if (kind == BA_QRKIT && world == 1) {
+        if ((kind == BA_QRKIT || kind == BA_QRSPQR) && world == 1) {
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
             for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
                 for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
@@ -1041,7 +1041,7 @@ int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar,
                      ba_solver **out)
 {
     if (!p || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return BA_ERR_ARG;
-    if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY && kind != BA_MOREQR) return BA_ERR_ARG;
+    if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY && kind != BA_MOREQR && kind != BA_QRSPQR) return BA_ERR_ARG;
     if (scalar != BA_F64 && scalar != BA_F32) return BA_ERR_ARG;
     *out = nullptr;
     int cnt = 0;

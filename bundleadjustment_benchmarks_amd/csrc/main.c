@@ -1,7 +1,7 @@
 /*
  * main.c -- drop-in for src/bundle_adjustment_large.cpp of jasvob/BundleAdjustment_Benchmarks: same command line
  * (`<exe> <sparse reconstruction file>`), exit codes (:26-31), stdout protocol (:61-171) and one executable per
- * solver symbol (-DQRKIT / -DQRCHOL / -DCHOLESKY / -DMOREQR, src/CMakeLists.txt:95-178); -DBA_SCALAR_FLOAT stands for
+ * solver symbol (-DQRKIT / -DQRCHOL / -DCHOLESKY / -DMOREQR / -DQRSPQR, src/CMakeLists.txt:95-178); -DBA_SCALAR_FLOAT stands for
  * `typedef float Scalar;` (src/BATypeUtils.h:6-7).  All work happens behind the C ABI of include/ba_mi355x.h.
  * Extensions: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking);
  * BA_CACHE=1 keeps a binary cache `<file>.bacache` of the parsed problem and reuses it when present;
@@ -24,8 +24,10 @@
 #define BA_KIND BA_CHOLESKY
 #elif defined(MOREQR)
 #define BA_KIND BA_MOREQR
+#elif defined(QRSPQR)
+#define BA_KIND BA_QRSPQR
 #else
-#error "define one of QRKIT, QRCHOL, CHOLESKY, MOREQR"
+#error "define one of QRKIT, QRCHOL, CHOLESKY, MOREQR, QRSPQR"
 #endif
 
 #ifdef BA_SCALAR_FLOAT

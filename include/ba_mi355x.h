@@ -37,7 +37,11 @@ enum {
 /* Solver symbols of the reference build (src/CMakeLists.txt:95-178; src/Optimization/BAFunctor.h:98-117).
  * BA_MOREQR (src/Eigen_ext/BacktrackLevMarqMore.h): two QR factorisations per step -- J once per outer iteration,
  * [R ; sqrt(lambda) I] per trial -- and lambda0 = 1e-6 * max column norm of J. */
-typedef enum { BA_QRKIT = 0, BA_QRCHOL = 1, BA_CHOLESKY = 2, BA_MOREQR = 3 } ba_solver_kind;
+/* BA_QRSPQR (SuiteSparseQR on the whole [J ; sqrt(lambda) I], BAFunctor.h:113-116, bundle_adjustment_large.cpp:151-157, README.md:17;
+ * the library itself is absent): a sparse QR of this matrix under a fill-reducing column ordering eliminates the 3-column point
+ * blocks first and is left with one dense front, J2bot -- which is the factorisation the QRKIT path performs, so the symbol runs
+ * that path (per-point Householder QR, dense Householder QR of J2bot); same LM loop as QRKIT (Eigen::BacktrackLevMarq). */
+typedef enum { BA_QRKIT = 0, BA_QRCHOL = 1, BA_CHOLESKY = 2, BA_MOREQR = 3, BA_QRSPQR = 4 } ba_solver_kind;
 
 /* `typedef double Scalar;` / `typedef float Scalar;` (src/BATypeUtils.h:6-7). */
 typedef enum { BA_F64 = 0, BA_F32 = 1 } ba_scalar;

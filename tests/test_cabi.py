@@ -160,7 +160,8 @@ def test_no_gpu_no_fallback(ba):
 
 
 @pytest.mark.parametrize("exe", ["Bundle_Adjustment_QRKit", "Bundle_Adjustment_QRChol", "Bundle_Adjustment_Cholesky",
-                                 "Bundle_Adjustment_Cholesky_f32", "Bundle_Adjustment_MoreQR", "Bundle_Adjustment_MoreQR_f32"])
+                                 "Bundle_Adjustment_Cholesky_f32", "Bundle_Adjustment_MoreQR", "Bundle_Adjustment_MoreQR_f32",
+                                 "Bundle_Adjustment_SPQR", "Bundle_Adjustment_QRKit_f32"])
 def test_executables_keep_reference_cli(exe):
     """Usage / exit codes of the reference driver (bundle_adjustment_large.cpp:26-31,45-54)."""
     path = os.path.join(BIN, exe)

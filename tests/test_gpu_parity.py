@@ -234,6 +234,18 @@ def test_qrkit_dense_qr_step_f64(ba, O, gpu_ok, small, prob21, src):
     assert np.array_equal(rg[:, :2], ro[:, :2]) and np.allclose(rg[:3, 2], ro[:3, 2], rtol=1e-7) and np.allclose(rg[:, 2], ro[:, 2], rtol=1e-4)
 
 
+def test_qrspqr_symbol_runs_the_whole_matrix_qr(ba, O, gpu_ok, small):
+    """QRSPQR (SuiteSparseQR on the whole [J ; sqrt(lambda) I]; library absent): the symbol runs the factorisation such a sparse QR
+    performs under a fill-reducing ordering -- per-point QR, then the dense front J2bot -- i.e. the QRKIT path: identical steps."""
+    a = ba.Solver(small, ba.QRSPQR, ba.F64)
+    b = ba.Solver(small, ba.QRKIT, ba.F64)
+    a.linearize(), b.linearize()
+    assert a.try_step(1e-3) == b.try_step(1e-3)
+    assert np.array_equal(a.get(ba.GET_DX), b.get(ba.GET_DX))
+    ra, rb = a.minimize(max_trials=5), b.minimize(max_trials=5)
+    assert np.array_equal(ra["trace"][:, :5], rb["trace"][:, :5])
+
+
 def test_f32_lm_decreases(ba, gpu_ok, prob39):
     s = ba.Solver(prob39, ba.QRCHOL, ba.F32)
     r = s.minimize(max_trials=15)
