@@ -59,9 +59,6 @@ template <int N, int T0, int T1, int T2, int T3> struct ba_tiles {
     static __device__ constexpr int t(int u) { return u == 0 ? T0 : u == 1 ? T1 : u == 2 ? T2 : T3; }
 };
 
-#ifdef BA_PERSIST_DBG
-__device__ long long ba_pdbg[64 * 4]; // k_ldlt_persist, per chain step: ticks waiting for the diagonal tile, for the sub-diagonal flag, of the whole step
-#endif
 // Diagnostic build only (-DBA_STAMP, scripts/bench_dense.hip): cycle stamps of the pivot loop's segments.
 #ifdef BA_STAMP
 __device__ long long ba_stamp_acc[8 * 8];
@@ -168,7 +165,7 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 // flags != nullptr (k_ldlt_step<INL = true>): the look-ahead update of this workgroup's 64 rows below is done by ANOTHER
 // workgroup of the same launch, which then stores `epoch` into flags[row block]; this workgroup waits for it just in front of
 // the row GEMM (the update takes ~6 us, the diagonal block ~20: the wait is a formality, bounded in any case).
-template <typename T, int NB, bool INL, bool HALVES = INL>
+template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                               T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel,
                                               const int *flags = nullptr, int epoch = 0, T *errw = nullptr)
@@ -257,9 +254,9 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         ba_wave_lds_order(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
     }
     BA_STAMP_PRO
-    // HALVES (= INL in the launch-per-step form, whose rows are updated by other workgroups): TWO panel workgroups per 64-row
-    // block, 32 rows each -- the row GEMM behind the factorisation is MFMA-bound (40 x 64 cycles per wave for 64 rows) and the CUs
-    // are there.  The one-launch form (k_ldlt_persist) has a single chain workgroup: INL without HALVES.
+    // INL (the variant whose rows are updated by other workgroups): TWO panel workgroups per 64-row block, 32 rows each -- the
+    // row GEMM behind the factorisation is MFMA-bound (40 x 64 cycles per wave for 64 rows) and the CUs are there.
+    constexpr bool HALVES = INL;
     const int rblk = HALVES ? (blk >> 1) : blk;
     const int rown = p0 + NB + 64 * rblk;
     const bool own_rows = Wprev != nullptr && rown < nrows;
@@ -452,14 +449,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // finished long ago; a wave with time to spare makes sure here, so that the L2 round trip of the check is not
                 // in front of the row GEMM -- every wave reads the rows behind the barriers that follow
                 int spins = 0;
-#ifdef BA_PERSIST_DBG
-                const long long tw0 = __builtin_readcyclecounter();
-#endif
                 while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < BA_FLAG_SPINS)
                     __builtin_amdgcn_s_sleep(4);
-#ifdef BA_PERSIST_DBG
-                if (epoch < 64) ba_pdbg[4 * epoch + 1] = __builtin_readcyclecounter() - tw0;
-#endif
                 // pairs with the release store of the row workgroup (k_ldlt_step): its rows are visible behind this fence
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 // A wait that ran out means the row GEMM below would read rows without their update: the factor would be finite
@@ -765,147 +756,6 @@ __global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int l
     ba_update_tile<T, NB, false>(ld, p0, row0, col0, ti == tj, S, Wp, nullptr);
 }
 
-// ---- the whole factorisation as ONE launch: a chain workgroup + tile workers, data flow through flags -----------------------
-// The launch-per-block-column form above pays, per step, a kernel boundary (~3.5 k cycles), a cold start (block fill + first
-// look-ahead tile, ~6 k) and a row GEMM that every panel workgroup finishes before the next launch may begin (~4 k) around the
-// ~22 k cycles the 64 pivots of a diagonal block really need.  Here workgroup 0 (the chain) walks the diagonal: it runs
-// ba_panel_body for block column p -- look-ahead update of the diagonal block by panel p - 1, factorisation, W = L11^-1, row GEMM
-// of the ONE row block p + 1 it needs next -- and goes straight on to p + 1.  The other workgroups own the tiles of the trailing
-// matrix (tile t = r (r + 1) / 2 + c belongs to worker t mod (G - 1)) and, panel by panel, do what the fused step's row and update
-// workgroups did: R(p, r): Y(r, p) = A(r, p) W_p^T, L = Y D^-1 for the row blocks r >= p + 2 (by the owner of tile (r, p)), then
-// U(p, r, c): A(r, c) -= Y(r, p) L(c, p)^T for their tiles behind column p.  Hand-offs, all through int flags in global memory
-// (data leave with write-through stores, s_waitcnt vmcnt(0) + barrier + release store of the flag; a consumer polls with one
-// lane, acquire fence, barrier):
-//   wready[p]        W_p, D_p published by the chain                                   -> R(p, .)
-//   rowready[p][r]   Y(r, p), L(r, p) published (chain: r = p + 1, workers: r >= p + 2)    -> U(p, r, .), U(p, ., r)
-//   diagdone[q]      panels 0 .. q - 2 applied to tile (q, q) by its owner                -> chain step q (which applies panel q - 1 itself)
-//   flags[q + 1] = q tile (q + 1, q) has panel q - 1 (the chain's row GEMM of step q reads it; ba_panel_body's own wait)
-// A tile's updates are ordered by its owner walking the panels in order; every wait is for something of a lower (panel, kind),
-// and every workgroup is resident (grid <= CUs, one workgroup per CU by its LDS), so the lowest unfinished task can always run.
-// Every wait is bounded and raises the device error word when it runs out.  Y panels: one per block column (nblk * ld * 64).
-template <typename T> __device__ __forceinline__ void ba_flag_wait(const int *f, int want, T *errw, int code)
-{
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < BA_FLAG_SPINS) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (invalidates this CU's vector L1: the plain loads behind the barrier see the producer's data)
-        if (spins >= BA_FLAG_SPINS && errw) __hip_atomic_store(errw, (T)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-}
-template <typename T> __device__ __forceinline__ void ba_flag_post(int *f, int value)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-#define BA_DEVERR_PERSIST 3 /* k_ldlt_persist: a hand-off between the chain and the tile workers never came */
-
-template <typename T, int NB>
-__global__ __launch_bounds__(256) void k_ldlt_persist(int nrows, int ncols, int ld, T *__restrict__ S, T *__restrict__ Wp /* nblk panels of ld * NB */,
-                                                      T *__restrict__ Winv, int *__restrict__ wready, int *__restrict__ rowready /* [nblk][nbr] */,
-                                                      int *__restrict__ diagdone, int *__restrict__ flags, T *__restrict__ errw)
-{
-    static_assert(NB == 64, "written for 64-wide block columns");
-    const int nblk = (ncols + NB - 1) / NB, nbr = (nrows + NB - 1) / NB;
-    const size_t wsz = (size_t)ld * NB;
-    if (blockIdx.x == 0) {
-        // ---- the chain
-        for (int p = 0; p < nblk; p++) {
-            const int p0 = p * NB;
-#ifdef BA_PERSIST_DBG
-            const long long ts0 = __builtin_readcyclecounter();
-#endif
-            if (p >= 2) ba_flag_wait<T>(&diagdone[p], p - 1, errw, BA_DEVERR_PERSIST); // tile (p, p) carries panels 0 .. p - 2
-            else __syncthreads();                                                           // (LDS of the previous step is free)
-#ifdef BA_PERSIST_DBG
-            const long long ts1 = __builtin_readcyclecounter();
-#endif
-            if (p == 1 && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // own step-0 outputs come back through L2
-            if (p == 1) __syncthreads();
-            ba_panel_body<T, NB, true, false>(nrows, ncols, ld, p0, S, Wp + (size_t)p * wsz, Winv + (size_t)p * NB * NB,
-                                              p > 0 ? Wp + (size_t)(p - 1) * wsz : (const T *)nullptr, 0, 1, flags, p, errw);
-            ba_flag_post<T>(&wready[p], 1);
-            if (p + 1 < nbr && threadIdx.x == 0) __hip_atomic_store(&rowready[(size_t)p * nbr + p + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef BA_PERSIST_DBG
-            if (threadIdx.x == 0 && p < 64) { ba_pdbg[4 * p] = ts1 - ts0; ba_pdbg[4 * p + 2] = __builtin_readcyclecounter() - ts0; }
-#endif
-        }
-        return;
-    }
-    // ---- tile workers
-    __shared__ T Ww[NB][NB + 1];
-    __shared__ T dinvw[NB];
-    const int nw = gridDim.x - 1, w = blockIdx.x - 1;
-    const int ntiles = nbr * (nbr + 1) / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
-    typedef typename ba_acc<T>::type acc_t;
-    for (int p = 0; p + 1 < nbr && p < nblk; p++) {
-        const int p0 = p * NB;
-        const bool full = ncols - p0 >= NB; // (a last, partial block column has no rows below that need Y: only the rhs rows, handled by the chain's own block)
-        // R tasks of this worker: tiles (r, p), r >= p + 2
-        bool have_w = false;
-        for (int t = w; t < ntiles && full; t += nw) {
-            int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (r * (r + 1) / 2 > t) r--;
-            while ((r + 1) * (r + 2) / 2 <= t) r++;
-            const int c = t - r * (r + 1) / 2;
-            if (c != p || r < p + 2) continue;
-            if (!have_w) { // W_p and D_p^-1 into LDS, once per panel
-                ba_flag_wait<T>(&wready[p], 1, errw, BA_DEVERR_PERSIST);
-                for (int idx = tid; idx < NB * NB; idx += 256) Ww[idx / NB][idx % NB] = Winv[(size_t)p * NB * NB + idx];
-                if (tid < NB) dinvw[tid] = ba_rcp(S[(size_t)(p0 + tid) * ld + p0 + tid]);
-                __syncthreads();
-                have_w = true;
-            }
-            // Y^T = W X^T for the 64 rows of row block r (wave wv: 16 rows, all four 16-wide column tiles), as in ba_panel_body
-            const int r0 = NB * r + 16 * wv;
-            if (r0 < nrows) {
-                const T *const px = S + (size_t)(p0 + lk) * ld + r0 + li;
-                acc_t acc[4];
-#pragma unroll
-                for (int tt = 0; tt < 4; tt++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) acc[tt][v] = 0;
-                T xall[NB / 4];
-#pragma unroll
-                for (int kk = 0; kk < NB / 4; kk++) xall[kk] = px[kk * (4 * (size_t)ld)];
-#pragma unroll
-                for (int kk = 0; kk < NB / 4; kk++) {
-                    const T xb = xall[kk];
-#pragma unroll
-                    for (int tt = 0; tt < 4; tt++)
-                        if (kk <= 4 * tt + 3) acc[tt] = ba_mfma(Ww[16 * tt + li][4 * kk + lk], xb, acc[tt]);
-                }
-                T *const wp = Wp + (size_t)p * wsz;
-#pragma unroll
-                for (int tt = 0; tt < 4; tt++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int j = 16 * tt + ba_crow<T>(lk, v);
-                        const T yv = acc[tt][v];
-                        __hip_atomic_store(&wp[(size_t)j * ld + r0 + li], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&S[(size_t)(p0 + j) * ld + r0 + li], yv * dinvw[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-            }
-            ba_flag_post<T>(&rowready[(size_t)p * nbr + r], 1);
-        }
-        // U tasks: own tiles behind column p (the chain applies panel p to the next diagonal tile itself)
-        for (int t = w; t < ntiles; t += nw) {
-            int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (r * (r + 1) / 2 > t) r--;
-            while ((r + 1) * (r + 2) / 2 <= t) r++;
-            const int c = t - r * (r + 1) / 2;
-            if (c <= p || c >= nblk || (r == p + 1 && c == p + 1)) continue;
-            ba_flag_wait<T>(&rowready[(size_t)p * nbr + r], 1, errw, BA_DEVERR_PERSIST);
-            if (c != r) ba_flag_wait<T>(&rowready[(size_t)p * nbr + c], 1, errw, BA_DEVERR_PERSIST);
-            ba_update_tile<T, NB, false, true>(ld, p0, NB * r, NB * c, r == c, S, Wp + (size_t)p * wsz, nullptr);
-            if (r == c) ba_flag_post<T>(&diagdone[r], p + 1);          // (panels 0 .. p are in; the chain wants r - 1 of them)
-            else if (r == c + 1 && p == c - 1) ba_flag_post<T>(&flags[r], c); // tile (c + 1, c) has panel c - 1: the chain's row GEMM of step c may read it
-        }
-    }
-}
-
 // Backward sweep L^T x = z, right-looking, one launch per block column (p0 descending).  z lives in row zrow of S.
 // Every workgroup first finishes the unknowns of block p0 (x_p = W_p^T z_p, a 64x64 GEMV, redundantly), workgroup 0
 // publishes them, then each wave eliminates them from its share of the earlier unknowns:
@@ -1178,19 +1028,9 @@ inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S,
 // block column (or panel + update launches for a single block column).  flags: nflags ints (hand-off flags of the row
 // workgroups), Wp: 2 * ld * NB (double-buffered Y = L D panel), Winv: one NB x NB inverse per block column.
 template <typename T, int NB>
-inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr,
-                           T *Wp_all = nullptr /* nblk panels: enables the one-launch form */, int *pflags = nullptr, int grid_persist = 0)
+inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr)
 {
     const int nblk = (ncols + NB - 1) / NB;
-    if (Wp_all && pflags && grid_persist >= 8 && nblk >= 2 && nblk < 48) {
-        // one launch (k_ldlt_persist): flags = [wready nblk | diagdone nblk | sub-diagonal flags nbr + 2 | rowready nblk * nbr]
-        const int nbr = (nrows + NB - 1) / NB;
-        const size_t nfl = (size_t)2 * nblk + nbr + 2 + (size_t)nblk * nbr;
-        (void)hipMemsetAsync(pflags, 0, sizeof(int) * nfl, st);
-        hipLaunchKernelGGL((k_ldlt_persist<T, NB>), dim3(grid_persist), dim3(256), 8192, st, nrows, ncols, ld, S, Wp_all, Winv, pflags, pflags + 2 * nblk + nbr + 2,
-                           pflags + nblk, pflags + 2 * nblk, errw);
-        return;
-    }
     const size_t wsz = (size_t)ld * NB;
     for (int p = 0; p < nblk; p++) {
         const int p0 = p * NB;

@@ -127,9 +127,6 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<T> d_cam[2], d_pts[2], d_meas, d_gcg, d_dslab, d_rec, d_dinv, d_tvec, d_tri,
         d_slab, d_S, d_pack, d_Skeep, d_Wp, d_Winv, d_dxc, d_dxp, d_part_e, d_part_pm, d_part_bs, d_part_st, d_scal;
     DevBuf<ba_lm_dev<T>> d_lm; // LM state of the device-side step control (k_lm_control)
-    DevBuf<T> d_Wp_all;        // one Y = L D panel per block column (the one-launch factorisation, k_ldlt_persist)
-    DevBuf<int> d_pflags;      // its hand-off flags
-    bool ldlt_persist = false;
     // QRKIT (single shard): dense J2bot (+ rhs column) for the Householder QR of the right block, its reflector scalars, the thin Q rows
     DevBuf<T> d_qA, d_qtau, d_q1obs, d_q1lam;
     size_t q_lda = 0, q_tau_stride = 0;
@@ -317,16 +314,6 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
         AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)2 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
-        {
-            const int nblk = (D + NB - 1) / NB, nbr = (D + 1 + NB - 1) / NB;
-            ldlt_persist = getenv("BA_LDLT_PERSIST") ? atoi(getenv("BA_LDLT_PERSIST")) != 0 : false;
-            if (ldlt_persist && nblk >= 2 && nblk < 48 && num_cus >= 8) {
-                AL(d_Wp_all, (size_t)nblk * ld * NB);
-                if ((rc = d_pflags.alloc((size_t)2 * nblk + nbr + 2 + (size_t)nblk * nbr))) return rc;
-                HIPCHK(hipMemset(d_Wp_all.p, 0, sizeof(T) * d_Wp_all.n));
-            } else
-                ldlt_persist = false;
-        }
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
 #undef AL
@@ -518,11 +505,7 @@ template <typename T> struct Solver final : SolverBase {
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
 
-    void launch_factor()
-    {
-        ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR, d_Wp_all.p, d_pflags.p,
-                              ldlt_persist ? num_cus : 0);
-    }
+    void launch_factor() { ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR); }
 
     // backward sweep: one data-flow launch (k_ldlt_backflow) while its groups are certainly co-resident
     void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR); }

@@ -35,26 +35,18 @@ int main(int argc, char **argv)
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     CK(hipMemset(Wp, 0, sizeof(double) * (size_t)2 * ld * NB));
     const int nflags = Dp / NB + 2; CK(hipMalloc(&flags, sizeof(int) * nflags)); CK(hipMemset(flags, 0, sizeof(int) * nflags));
-    // one-launch form (k_ldlt_persist): a Y panel per block column, its hand-off flags, a device error word
-    const int nblk_ = (D + NB - 1) / NB, nbr_ = (D + 1 + NB - 1) / NB;
-    double *Wp_all, *errw; int *pflags;
-    CK(hipMalloc(&Wp_all, sizeof(double) * (size_t)nblk_ * ld * NB)); CK(hipMemset(Wp_all, 0, sizeof(double) * (size_t)nblk_ * ld * NB));
-    CK(hipMalloc(&pflags, sizeof(int) * ((size_t)2 * nblk_ + nbr_ + 2 + (size_t)nblk_ * nbr_)));
-    CK(hipMalloc(&errw, sizeof(double))); CK(hipMemset(errw, 0, sizeof(double)));
-    int ncu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess) ncu = pr.multiProcessorCount; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
     const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
     float tp = 0, tu = 0, tb = 0, tot = 0;
     std::vector<double> xs_h(D);
     const int reps = 5;
-    for (int fused = 0; fused < 3; fused++) { // 0: launch per panel + per update, 1: fused look-ahead step per block column, 2: one launch
+    for (int fused = 0; fused < 2; fused++) {
     tot = 0; tb = 0;
     for (int rep = 0; rep < reps + 1; rep++) {
         CK(hipMemcpyAsync(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
-        if (fused == 2) ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags, errw, Wp_all, pflags, ncu);
-        else if (fused) ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags); // the product's launch sequence
+        if (fused) ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags); // the product's launch sequence
         else for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
             hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB, flags, nflags);
@@ -78,14 +70,8 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(xs_h.data(), x, sizeof(double) * D, hipMemcpyDeviceToHost));
     { double rn = 0, bn = 0; for (int r = 0; r < D; r++) { double a = 0; for (int c = 0; c < D; c++) a += (c <= r ? h[(size_t)c * ld + r] : h[(size_t)r * ld + c]) * xs_h[c]; const double b = h[(size_t)r * ld + D]; rn += (a - b) * (a - b); bn += b * b; }
-      double ew = 0; CK(hipMemcpy(&ew, errw, sizeof(double), hipMemcpyDeviceToHost));
-      printf("%s: D=%d factor %.3f ms  backsweep %.3f ms  residual %.2e  device error word %g\n", fused == 2 ? "one launch (chain + workers)" : fused ? "fused look-ahead" : "separate launches", D, tot / reps, tb / reps, std::sqrt(rn / bn), ew); }
+      printf("%s: D=%d factor %.3f ms  backsweep %.3f ms  residual %.2e\n", fused ? "fused look-ahead" : "separate launches", D, tot / reps, tb / reps, std::sqrt(rn / bn)); }
     }
-#ifdef BA_PERSIST_DBG
-    { long long hp[256]; CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(ba_pdbg), sizeof(hp)));
-      printf("chain steps (s_memtime ticks = 100 MHz? see ratio): step: wait diagonal | wait sub-diagonal flag | whole step\n");
-      for (int q = 0; q < nblk_ && q < 64; q++) printf("  %2d: %8lld %8lld %8lld\n", q, hp[4 * q], hp[4 * q + 1], hp[4 * q + 2]); }
-#endif
     // panel-only and update-only timings at p0 = 0
     CK(hipMemcpy(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
     CK(hipEventRecord(e0, st));
