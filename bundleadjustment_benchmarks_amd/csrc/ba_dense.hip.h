@@ -138,10 +138,10 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
 
 template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1]);
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], const T *__restrict__ Wp2 = nullptr, int p02 = 0);
 template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad);
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad, const T *__restrict__ Wp2 = nullptr, int p02 = 0);
 template <typename T, int NB>
 __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, int row0t, int col0t, T *S, const T *Wp, int quad);
 
@@ -636,7 +636,8 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 template <typename T, int NB, bool INL>
 __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
                                                    T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
-                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr)
+                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr,
+                                                   int upd_mode = 0, const T *__restrict__ Wprev2 = nullptr)
 {
     int bid = blockIdx.x;
     if (INL && bid < nq) {
@@ -653,19 +654,31 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
         ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, INL ? flags : nullptr, p0 / NB, errw);
         return;
     }
-    // tile u of the set {(ti, tj): 1 <= tj <= ti, tj < ntc}, rows p0 + 64 ti, columns p0 + 64 tj
+    // Trailing update by the workgroups behind the panel workgroups.  upd_mode 0: panel p - 1 on every tile of the set
+    // {(ti, tj): 1 <= tj <= ti, tj < ntc} (rows p0 + 64 ti, columns p0 + 64 tj).  Large matrices (config 5) alternate instead:
+    // upd_mode 1 (even steps): panel p - 1 on the NEXT block column only (tj = 1: the one the next step factors); upd_mode 2 (odd
+    // steps): panels p - 2 and p - 1 together on every tile (K = 128: the trailing matrix is read and written every second step).
+    // Measured at D = 9216: 9.4 against 10.0 ms -- the update is bound by the L2 traffic of its operands (one 8-byte load per lane
+    // and MFMA) as much as by the C tiles.  A 128 x 128 macro tile with the operands staged through LDS (4x less L2 traffic) was
+    // built and measured too: 10.5 ms -- next to the panel's 77 KiB its LDS leaves one workgroup per CU, and then nothing overlaps
+    // the 256 KiB of C traffic per tile (10 us) with its 14 us of MFMAs.  What it takes is that update as a kernel of its own
+    // (two workgroups per CU) running beside the panel launch; not built.
     const int ntc = (ncols - p0 + 63) / 64;
-    int u = bid - npanel, ti = 1;
-    for (;; ti++) {
-        const int cnt = min(ti, ntc - 1);
-        if (u < cnt) break;
-        u -= cnt;
+    int u = bid - npanel, ti = 1, tj;
+    if (upd_mode == 1) { ti = 1 + u; tj = 1; }
+    else {
+        for (;; ti++) {
+            const int cnt = min(ti, ntc - 1);
+            if (u < cnt) break;
+            u -= cnt;
+        }
+        tj = 1 + u;
     }
-    const int tj = 1 + u;
     const int row0 = p0 + 64 * ti, col0 = p0 + 64 * tj;
     if (row0 >= nrows || col0 >= ncols) return;
     // (write-through stores: the 17 MB a launch writes leave the L2s while it runs, not in the release at its end)
-    ba_update_tile<T, NB, false, true>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
+    if (upd_mode == 2 && Wprev2) ba_update_tile<T, NB, false, true>(ld, p0 - 2 * NB, row0, col0, ti == tj, S, Wprev2, nullptr, Wprev, p0 - NB);
+    else ba_update_tile<T, NB, false, true>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
 }
 
 // Trailing update of one 64 x 64 tile with the 64-wide panel at block column p0: C_ij -= sum_k Y_ik L_jk.
@@ -676,9 +689,11 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
 // flight at once to cover the L2 latency.  LOWER: skip the strictly upper quadrant (diagonal tiles).
 // TOLDS: the C tile lives in the LDS image Cl[col][row] (64 x 65) instead of S (diagonal block inside the panel step).
 // STSC: the results leave with agent-scope (sc1, write-through) stores: another workgroup of the SAME launch reads them.
+// Wp2 != nullptr: a SECOND panel (block column p02, Y in Wp2) is applied in the same pass over the tile -- K = 128: the tile is
+// read and written once for two panels, which halves the traffic of the C tiles that bounds the update of a large matrix.
 template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad)
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad, const T *__restrict__ Wp2, int p02)
 {
     const int lane = threadIdx.x & 63;
     const int qr = 32 * (quad >> 1), qc = 32 * (quad & 1);
@@ -698,23 +713,27 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
     // k-steps whose operands are in flight together: all sixteen for the diagonal block (latency: it is on the critical
     // path), eight for the trailing tiles (throughput: registers)
     constexpr int CH = TOLDS ? NB / 4 : ((NB / 4 < 8) ? NB / 4 : 8);
+    for (int pass = 0; pass < (Wp2 ? 2 : 1); pass++) { // (uniform)
+        const T *const Wq = pass ? Wp2 : Wp;
+        const int pq = pass ? p02 : p0;
 #pragma unroll
-    for (int half = 0; half < (NB / 4) / CH; half++) {
-        T a[CH][2], b[CH][2];
+        for (int half = 0; half < (NB / 4) / CH; half++) {
+            T a[CH][2], b[CH][2];
 #pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const int kk = CH * half + q;
+            for (int q = 0; q < CH; q++) {
+                const int kk = CH * half + q;
 #pragma unroll
-            for (int t = 0; t < 2; t++) a[q][t] = S[(size_t)(p0 + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k] (negated at use)
+                for (int t = 0; t < 2; t++) a[q][t] = S[(size_t)(pq + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k] (negated at use)
 #pragma unroll
-            for (int u = 0; u < 2; u++) b[q][u] = Wp[(size_t)(4 * kk + lk) * ld + row0 + 16 * u + li];        // B[k][i] = Y[i][k]
+                for (int u = 0; u < 2; u++) b[q][u] = Wq[(size_t)(4 * kk + lk) * ld + row0 + 16 * u + li];        // B[k][i] = Y[i][k]
+            }
+#pragma unroll
+            for (int q = 0; q < CH; q++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(-a[q][t], b[q][u], acc[t][u]);
         }
-#pragma unroll
-        for (int q = 0; q < CH; q++)
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(-a[q][t], b[q][u], acc[t][u]);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -731,9 +750,9 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
 
 template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1])
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], const T *__restrict__ Wp2, int p02)
 {
-    ba_update_quad<T, NB, TOLDS, STSC>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6); // wave w owns quadrant w
+    ba_update_quad<T, NB, TOLDS, STSC>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6, Wp2, p02); // wave w owns quadrant w
 }
 
 // Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
@@ -1032,11 +1051,13 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
 {
     const int nblk = (ncols + NB - 1) / NB;
     const size_t wsz = (size_t)ld * NB;
+    const bool k128 = nblk >= 48; // update-bound sizes: two panels per pass over the trailing matrix (Wp: THREE panels, p % 3)
     for (int p = 0; p < nblk; p++) {
         const int p0 = p * NB;
         const int below = nrows - (p0 + NB);
         const int npanel = below > 0 ? (below + 63) / 64 : 1;
-        T *wcur = Wp + (size_t)(p & 1) * wsz, *wprev = Wp + (size_t)((p + 1) & 1) * wsz;
+        T *wcur = Wp + (size_t)(k128 ? p % 3 : (p & 1)) * wsz, *wprev = Wp + (size_t)(k128 ? (p + 2) % 3 : ((p + 1) & 1)) * wsz;
+        const T *wprev2 = Wp + (size_t)((p + 1) % 3) * wsz; // (k128 only) panel p - 2
         // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
         // and keeps the previous panel's update off the diagonal block's path.
         const bool fused = nblk >= 2;
@@ -1062,9 +1083,13 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
                 const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
                 hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2, S, wcur,
                                    wprev, Winv + (size_t)p * NB * NB, nq, flags, errw);
-            } else
-                hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + nupd), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, S, wcur,
-                                   wprev, Winv + (size_t)p * NB * NB, 0, (int *)nullptr, errw);
+            } else {
+                // step 1: the only panel there is; then even steps update the next block column alone, odd steps everything with two panels
+                const int mode = p == 1 ? 0 : (p & 1) ? 2 : 1;
+                const int ng = mode == 1 ? (ntc > 1 ? nt - 1 : 0) : nupd;
+                hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + ng), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, S, wcur,
+                                   wprev, Winv + (size_t)p * NB * NB, 0, (int *)nullptr, errw, mode, wprev2);
+            }
         }
     }
 }

@@ -30,10 +30,10 @@ int main(int argc, char **argv)
     double *S, *Wp, *Winv, *x, *S0; int *flags;
     long long *stamps;
     CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
-    CK(hipMalloc(&Wp, sizeof(double) * (size_t)2 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
+    CK(hipMalloc(&Wp, sizeof(double) * (size_t)3 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
     CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)2 * ld * NB));
+    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)3 * ld * NB));
     const int nflags = Dp / NB + 2; CK(hipMalloc(&flags, sizeof(int) * nflags)); CK(hipMemset(flags, 0, sizeof(int) * nflags));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
