@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
                                                  const T *__restrict__ lam, T *__restrict__ rec, T *__restrict__ dinv,
                                                  T *__restrict__ tvec, T *__restrict__ tri, const int *__restrict__ go = nullptr,
                                                  T *__restrict__ q1obs = nullptr /* [K][6]: thin Q rows per observation (QRKIT) */,
-                                                 T *__restrict__ q1lam = nullptr /* [Ml][9]: thin Q rows of the lambda rows */)
+                                                 T *__restrict__ q1lam = nullptr /* [Ml][9]: thin Q rows of the lambda rows */,
+                                                 int *__restrict__ pperm = nullptr /* [Ml]: column permutation p0 | p1 << 2 | p2 << 4 */)
 {
     if (go && *go == 0) return; // (MOREQR's outer factorisation is part of the conditional linearisation)
     // the points of one track-length bucket (pt_list; the host buckets them so that a short track does not occupy the lanes
@@ -432,13 +433,44 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
 #pragma unroll
         for (int q = 0; q < 6; q++) { V[s][q] = ok[s] ? Jp[(size_t)q * K + i] : (T)0; Q[s][q] = 0; }
     }
+    // Column pivoting like the reference's dense block solver (ColPivHouseholderQR, BAFunctor.h:99,104): every step takes the
+    // remaining column of largest norm.  The remaining columns all carry the same sqrt(lambda) in their own (untouched) lambda
+    // row, so the comparison is between the observation parts; the first maximum wins a tie.  A step's choice is the same in all
+    // lanes of a point's group (group sums), so the swaps are selects on registers; perm[c] = original index of the column in
+    // position c, undone in k_backsub (colsPermutation(), BacktrackLevMarqQRChol.h:360).
     T R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tau[3];
+    int perm[3] = {0, 1, 2};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        T xn = 0;
+        T nrm[3] = {0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < SL; s++) xn += V[s][c] * V[s][c] + V[s][3 + c] * V[s][3 + c];
-        xn = group_sum<T, LPP>(xn);
+        for (int c2 = c; c2 < 3; c2++) {
+#pragma unroll
+            for (int s = 0; s < SL; s++) nrm[c2] += V[s][c2] * V[s][c2] + V[s][3 + c2] * V[s][3 + c2];
+            nrm[c2] = group_sum<T, LPP>(nrm[c2]);
+        }
+        int best = c;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 3; c2++)
+            if (nrm[c2] > nrm[best]) best = c2;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 3; c2++) { // (best is lane-varying between the groups of a wave: swap by selects)
+            const bool sw = best == c2;
+#pragma unroll
+            for (int s = 0; s < SL; s++) {
+                const T a0 = V[s][c], a1 = V[s][3 + c];
+                V[s][c] = sw ? V[s][c2] : a0; V[s][c2] = sw ? a0 : V[s][c2];
+                V[s][3 + c] = sw ? V[s][3 + c2] : a1; V[s][3 + c2] = sw ? a1 : V[s][3 + c2];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+                if (rr < c) { const T t0 = R[rr][c]; R[rr][c] = sw ? R[rr][c2] : t0; R[rr][c2] = sw ? t0 : R[rr][c2]; }
+            const int p0 = perm[c];
+            perm[c] = sw ? perm[c2] : p0; perm[c2] = sw ? p0 : perm[c2];
+            const T n0 = nrm[c];
+            nrm[c] = sw ? nrm[c2] : n0; nrm[c2] = sw ? n0 : nrm[c2];
+        }
+        const T xn = nrm[c];
         const T alpha = sl;                        // the lambda row c is untouched by the earlier reflectors
         const T beta = -tsqrt(alpha * alpha + xn); // alpha >= 0
         // beta == 0: a zero column, possible only with lambda = 0 (MOREQR stage 1, point without observations):
@@ -495,6 +527,7 @@ __global__ __launch_bounds__(256) void k_elim_qr(int npts, const int *__restrict
         for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = q1[c]; }
         tri[j] = R[0][0]; tri[(size_t)Ml + j] = R[0][1]; tri[2 * (size_t)Ml + j] = R[0][2];
         tri[3 * (size_t)Ml + j] = R[1][1]; tri[4 * (size_t)Ml + j] = R[1][2]; tri[5 * (size_t)Ml + j] = R[2][2];
+        if (pperm) pperm[j] = perm[0] | (perm[1] << 2) | (perm[2] << 4);
         if (q1lam) {
 #pragma unroll
             for (int h = 0; h < 3; h++)
@@ -846,7 +879,7 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
                                                  const T *__restrict__ rec, const T *__restrict__ dinv, const T *__restrict__ tvec,
                                                  const T *__restrict__ tri, const T *__restrict__ dxc, const T *__restrict__ gp,
                                                  const T *__restrict__ pts, const T *__restrict__ lam, T *__restrict__ dxp, T *__restrict__ pts_test,
-                                                 T *__restrict__ partial /* [2][grid] */)
+                                                 T *__restrict__ partial /* [2][grid] */, const int *__restrict__ pperm /* column permutation of the point's 3x3 block */)
 {
     // LPP lanes per point: each lane forms Z_i^T dx_c for its observations (i = g, g + LPP, ...), a butterfly sum over
     // the group gives the point's 3-vector, lane 0 of the group finishes the 3x3 triangular solve.
@@ -875,9 +908,12 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
         const T lambda = *lam;
         const T u0 = (tvec[j] - s0) * dinv[j], u1 = (tvec[(size_t)Ml + j] - s1) * dinv[(size_t)Ml + j],
                 u2 = (tvec[2 * (size_t)Ml + j] - s2) * dinv[2 * (size_t)Ml + j];
-        const T x2 = u2 / tri[5 * (size_t)Ml + j];
-        const T x1 = (u1 - tri[4 * (size_t)Ml + j] * x2) / tri[3 * (size_t)Ml + j];
-        const T x0 = (u0 - tri[(size_t)Ml + j] * x1 - tri[2 * (size_t)Ml + j] * x2) / tri[j];
+        const T y2 = u2 / tri[5 * (size_t)Ml + j];
+        const T y1 = (u1 - tri[4 * (size_t)Ml + j] * y2) / tri[3 * (size_t)Ml + j];
+        const T y0 = (u0 - tri[(size_t)Ml + j] * y1 - tri[2 * (size_t)Ml + j] * y2) / tri[j];
+        // m_dx = colsPermutation() * m_dx (BacktrackLevMarqQRChol.h:360): position c of the pivoted block is coordinate perm[c]
+        const int pp = pperm[j], q0 = pp & 3, q1 = (pp >> 2) & 3;
+        const T x0 = q0 == 0 ? y0 : q1 == 0 ? y1 : y2, x1 = q0 == 1 ? y0 : q1 == 1 ? y1 : y2, x2 = q0 == 2 ? y0 : q1 == 2 ? y1 : y2;
         dxp[j] = x0; dxp[(size_t)Ml + j] = x1; dxp[2 * (size_t)Ml + j] = x2;
         pts_test[j] = pts[j] + x0;
         pts_test[(size_t)Ml + j] = pts[(size_t)Ml + j] + x1;

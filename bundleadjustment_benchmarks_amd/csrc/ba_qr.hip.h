@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
     __shared__ T sc_s[4];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
+#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
     for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
         const int c = idx / CH, l = idx - c * CH;
         T v = 0;
@@ -142,10 +143,18 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
         for (int l = j + 1 + tid; l < rows; l += 256) Ac[j][l] *= sc;
         if (tid == 0) Ac[j][j] = sc_s[2];
         __syncthreads();
-        // w_c = tau (a_c[j] + v . a_c) for the columns behind j, then a_c -= v w_c
+        // w_c = tau (a_c[j] + v . a_c) for the columns behind j, then a_c -= v w_c.  Fixed trip counts, unrolled: the LDS reads of
+        // sixteen rows are in flight together (a rolled loop paid the LDS latency per row: 11 us per column).  Rows <= j hold R
+        // entries of column j, not reflector entries: masked.
         T dot = 0;
-        if (cc > j && cc < bw)
-            for (int l = j + 1 + rg; l < rows; l += 8) dot += Ac[j][l] * Ac[cc][l];
+        if (cc > j && cc < bw) {
+#pragma unroll 16
+            for (int it = 0; it < CH / 8; it++) {
+                const int l = rg + 8 * it;
+                const T v = l > j ? Ac[j][l] : (T)0; // (rows beyond the chunk's last sub-block are zero-filled)
+                dot += v * Ac[cc][l];
+            }
+        }
         red[rg][cc] = dot;
         __syncthreads();
         if (cc > j && cc < bw) {
@@ -153,11 +162,17 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
 #pragma unroll
             for (int q = 0; q < 8; q++) d += red[q][cc];
             const T w = tj * (Ac[cc][j] + d);
-            for (int l = j + 1 + rg; l < rows; l += 8) Ac[cc][l] -= Ac[j][l] * w;
+#pragma unroll 16
+            for (int it = 0; it < CH / 8; it++) {
+                const int l = rg + 8 * it;
+                const T v = l > j ? Ac[j][l] : (T)0;
+                Ac[cc][l] -= v * w;
+            }
             if (rg == 0) Ac[cc][j] -= w;
         }
         __syncthreads();
     }
+#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
     for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
         const int c = idx / CH, l = idx - c * CH;
         if (c < bw && l < rows && (level == 1 || (l & 31) <= c)) A[(size_t)(c0 + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = Ac[c][l];
@@ -179,32 +194,53 @@ __global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda,
     const int g = blockIdx.x, tid = threadIdx.x;
     const int cb = col0 + BA_QR_PB * blockIdx.y, ncol = min(BA_QR_PB, col1 - cb);
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
+#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
     for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
         const int c = idx / CH, l = idx - c * CH;
         B[c][l] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] : (T)0;
     }
     const int cc = tid & 31, rg = tid >> 5;
+    // reflector j as this thread's CH / 256 rows of it (l = tid + 256 e): 1 at row j, zero above, the stored entries below
+    auto vload = [&](int j, T (&v)[CH / 256]) {
+#pragma unroll
+        for (int e = 0; e < CH / 256; e++) {
+            const int l = tid + 256 * e;
+            T x = 0;
+            if (l == j) x = 1;
+            else if (l > j && l < rows && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j)))
+                x = A[(size_t)(c0 + j) * lda + ba_qr_row<T>(row0, g, l, stride)];
+            v[e] = x;
+        }
+    };
+    T vn[CH / 256];
+    vload(0, vn);
     for (int j = 0; j < bw; j++) {
         const T tj = tau[(size_t)g * BA_QR_PB + j];
         __syncthreads(); // (the previous reflector's reads of vs, and the fill of B on the first pass)
-        for (int l = tid; l < rows; l += 256) {
-            T v = 0;
-            if (l == j) v = 1;
-            else if (l > j && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j))) v = A[(size_t)(c0 + j) * lda + ba_qr_row<T>(row0, g, l, stride)];
-            vs[l] = v;
-        }
+#pragma unroll
+        for (int e = 0; e < CH / 256; e++) vs[tid + 256 * e] = vn[e];
+        if (j + 1 < bw) vload(j + 1, vn); // the next reflector comes in from L2 under this one's arithmetic
         __syncthreads();
         T dot = 0;
-        for (int l = j + rg; l < rows; l += 8) dot += vs[l] * B[cc][l];
+#pragma unroll 16
+        for (int it = 0; it < CH / 8; it++) {
+            const int l = rg + 8 * it;
+            dot += vs[l] * B[cc][l]; // (vs is zero above row j and beyond the chunk's rows)
+        }
         red[rg][cc] = dot;
         __syncthreads();
         T d = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) d += red[q][cc];
         const T w = tj * d;
-        for (int l = j + rg; l < rows; l += 8) B[cc][l] -= vs[l] * w;
+#pragma unroll 16
+        for (int it = 0; it < CH / 8; it++) {
+            const int l = rg + 8 * it;
+            B[cc][l] -= vs[l] * w;
+        }
     }
     __syncthreads();
+#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
     for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
         const int c = idx / CH, l = idx - c * CH;
         if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = B[c][l];

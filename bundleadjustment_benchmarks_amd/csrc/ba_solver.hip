@@ -114,7 +114,7 @@ template <typename T> struct Solver final : SolverBase {
     T tau = (T)0.5; // INLIER_THRESHOLD, src/bundle_adjustment_large.cpp:36
     // structure
     DevBuf<int> d_obs_cam, d_obs_pt, d_pt_ptr, d_pair_hi, d_pair_lo, d_pair_chunk_ptr,
-        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags;
+        d_dchunk_ptr, d_cam_dchunk_ptr, d_cam_obs, d_qr_pts, d_flags, d_pperm /* column permutation of every point's 3x3 block */;
     DevBuf<int4> d_chunk_info; // per chunk of the pair kernel: first entry, count | BA_CHUNK_SINGLE, cameras hi | lo << 16, chunk id
     DevBuf<int2> d_ent;        // per entry: row observation, column observation (~point for a self entry)
     DevBuf<int> d_wave_ptr;    // per wavefront of the pair kernel: its range of chunk descriptors
@@ -298,6 +298,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_V, (size_t)81 * N); AL(d_gc, (size_t)D);
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
+        if ((rc = d_pperm.upload(std::vector<int>(M1, 0 | (1 << 2) | (2 << 4))))) return rc; // identity (CHOLESKY never pivots)
         if ((kind == BA_QRKIT || kind == BA_QRSPQR) && world == 1) {
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
             for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
@@ -462,7 +463,7 @@ template <typename T> struct Solver final : SolverBase {
         if (sx.qr_bucket_ptr[B + 1] > sx.qr_bucket_ptr[B]) {                                                                   \
             const int np_ = sx.qr_bucket_ptr[B + 1] - sx.qr_bucket_ptr[B];                                                       \
             hipLaunchKernelGGL((k_elim_qr<T, L, SLOTS>), dim3(((size_t)np_ * L + 255) / 256), dim3(256), 0, st, np_,           \
-                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri, go, qo, ql); \
+                               d_qr_pts.p + sx.qr_bucket_ptr[B], Ml, Kl, d_pt_ptr.p, d_Jc.p, d_Jp.p, d_r.p, lam, rec, dinv, tvec, tri, go, qo, ql, d_pperm.p); \
         }
         BA_QR(0, 8, 4)
         BA_QR(1, 16, 4)
@@ -526,7 +527,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (Ml > 0) // (an empty shard keeps the zero partial sums written at creation)
         hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
-                           d_tri.p, d_dxc.p, d_gp.p, d_pts[0].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1].p, d_part_bs.p);
+                           d_tri.p, d_dxc.p, d_gp.p, d_pts[0].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1].p, d_part_bs.p, d_pperm.p);
         hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[0].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
                            d_cam[1].p, d_scal.p, (int)SC_RHO_C);
     }

@@ -347,6 +347,7 @@ static void FN(dense_qr_solve)(int m, int n, S *A, S *b, S *x)
  *          dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i])). */
 typedef struct {
     S *Z, *dinv, *t, *tri;
+    int *perm; /* 3 per point (may be NULL = identity): position c of the point's pivoted 3x3 block is coordinate perm[c] */
 } FN(elim_t);
 
 /* CHOLESKY: block elimination of the point variables from (J^T J + lambda I) -- identical to LDL^T of
@@ -419,7 +420,23 @@ static void FN(elim_qr)(int M, const int *pt_ptr, const S *Jc, const S *Jp, cons
         for (int c = 0; c < 3; c++)
             for (int r = 0; r < 3; r++) Wk[c * m + 2 * k + r] = (r == c) ? sl : (S)0;
         S tau[3];
+        int perm[3] = {0, 1, 2};
         for (int c = 0; c < 3; c++) {
+            /* ColPivHouseholderQR (BAFunctor.h:99,104): the remaining column of largest norm (rows c..m-1) comes next; the
+             * first maximum wins a tie; colsPermutation() is undone in backsub (BacktrackLevMarqQRChol.h:360) */
+            {
+                int best = c;
+                S nbest = -1;
+                for (int c2 = c; c2 < 3; c2++) {
+                    S nn = 0;
+                    for (int r = c; r < m; r++) nn += Wk[c2 * m + r] * Wk[c2 * m + r];
+                    if (nn > nbest) { nbest = nn; best = c2; }
+                }
+                if (best != c) {
+                    for (int r = 0; r < m; r++) { const S t_ = Wk[c * m + r]; Wk[c * m + r] = Wk[best * m + r]; Wk[best * m + r] = t_; }
+                    const int p_ = perm[c]; perm[c] = perm[best]; perm[best] = p_;
+                }
+            }
             S *col = Wk + c * m;
             S xn = 0;
             for (int r = c + 1; r < m; r++) xn += col[r] * col[r];
@@ -461,6 +478,7 @@ static void FN(elim_qr)(int M, const int *pt_ptr, const S *Jc, const S *Jp, cons
         dinv[0] = dinv[1] = dinv[2] = 1;
         tri[0] = Wk[0]; tri[1] = Wk[m]; tri[2] = Wk[2 * m]; tri[3] = Wk[m + 1]; tri[4] = Wk[2 * m + 1];
         tri[5] = Wk[2 * m + 2];
+        if (e->perm) { e->perm[3 * (size_t)j] = perm[0]; e->perm[3 * (size_t)j + 1] = perm[1]; e->perm[3 * (size_t)j + 2] = perm[2]; }
         S q1[3] = {0, 0, 0};
         for (int i = 0; i < k; i++) {
             const S *A = Jc + 18 * (size_t)(i0 + i);
@@ -498,13 +516,14 @@ typedef struct {
     S *R12T; /* K x 27: R12_i^T (9x3 row-major) */
     S *R1;   /* M x 6 upper triangle 00 01 02 11 12 22 */
     S *mq1;  /* M x 3: -q1 */
+    int *perm; /* M x 3: column permutation of the outer factorisation */
 } FN(more_t);
 
 static void FN(more_outer)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, FN(more_t) * o)
 {
     FN(elim_t) e;
     int K = pt_ptr[M];
-    e.Z = o->R12T; e.tri = o->R1; e.t = o->mq1;
+    e.Z = o->R12T; e.tri = o->R1; e.t = o->mq1; e.perm = o->perm;
     e.dinv = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
     (void)K;
     FN(elim_qr)(M, pt_ptr, Jc, Jp, fvec, (S)0, &e, NULL, NULL); /* lambda = 0: QR of [B;0] */
@@ -625,7 +644,12 @@ static void FN(backsub)(int M, const int *pt_ptr, const int *cam_idx, const FN(e
         const S x2 = u[2] / tri[5];
         const S x1 = (u[1] - tri[4] * x2) / tri[3];
         const S x0 = (u[0] - tri[1] * x1 - tri[2] * x2) / tri[0];
-        dx[3 * (size_t)j] = x0; dx[3 * (size_t)j + 1] = x1; dx[3 * (size_t)j + 2] = x2;
+        if (e->perm) { /* m_dx = colsPermutation() * m_dx, BacktrackLevMarqQRChol.h:360 */
+            const int *pp = e->perm + 3 * (size_t)j;
+            dx[3 * (size_t)j + pp[0]] = x0; dx[3 * (size_t)j + pp[1]] = x1; dx[3 * (size_t)j + pp[2]] = x2;
+        } else {
+            dx[3 * (size_t)j] = x0; dx[3 * (size_t)j + 1] = x1; dx[3 * (size_t)j + 2] = x2;
+        }
     }
 }
 
@@ -749,6 +773,8 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     e.dinv = (S *)malloc(sizeof(S) * 3 * (size_t)M);
     e.t = (S *)malloc(sizeof(S) * 3 * (size_t)M);
     e.tri = (S *)malloc(sizeof(S) * 6 * (size_t)M);
+    e.perm = (int *)malloc(sizeof(int) * 3 * (size_t)(M > 0 ? M : 1));
+    for (size_t q_ = 0; q_ < 3 * (size_t)M; q_++) e.perm[q_] = (int)(q_ % 3); /* identity unless a QR symbol pivots */
     S *Smat = (S *)malloc(sizeof(S) * (size_t)D * D);
     S *rhs = (S *)malloc(sizeof(S) * (size_t)D);
     S *gc = (S *)malloc(sizeof(S) * (size_t)D);
@@ -763,6 +789,7 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
         o.R12T = (S *)malloc(sizeof(S) * 27 * (size_t)(K > 0 ? K : 1));
         o.R1 = (S *)malloc(sizeof(S) * 6 * (size_t)(M > 0 ? M : 1));
         o.mq1 = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
+        o.perm = e.perm; /* the outer QR's column permutation carries through the inner QR to the step */
         FN(more_outer)(M, pt_ptr, Jc, Jp, fvec, &o);
         FN(more_trial)(M, pt_ptr, lambda, &o, &e);
         free(o.R12T); free(o.R1); free(o.mq1);
@@ -789,7 +816,7 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     if (!assemble_only) FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
     if (gout || diagmax) FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, gout, diagmax);
     free(Q1obs); free(Q1lam);
-    free(e.Z); free(e.dinv); free(e.t); free(e.tri);
+    free(e.Z); free(e.dinv); free(e.t); free(e.tri); free(e.perm);
     free(Smat); free(rhs); free(gc); free(pt_ptr);
     return rc;
 }

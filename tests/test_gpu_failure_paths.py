@@ -28,3 +28,34 @@ def test_selftest_refuses_a_single_group(ba, gpu_ok):
     p = ba.Problem.synthetic(6, 100, 400, 3)  # D = 54: one block column, nobody to wait for
     s = ba.Solver(p, ba.QRCHOL, ba.F64)
     assert s.selftest(1) == 4
+
+
+def test_legacy_stream_falls_back_to_direct_launches(ba, O, gpu_ok):
+    """ba_solver_set_stream(NULL) hands the solver the legacy default stream, which cannot be captured into a hipGraph:
+    ba_minimize must then enqueue the same kernels directly (same device-side control) and give the same run."""
+    p = ba.Problem.synthetic(10, 400, 1500, 8)
+    ref = ba.Solver(p, ba.QRCHOL, ba.F64).minimize(max_trials=8)
+    s = ba.Solver(p, ba.QRCHOL, ba.F64)
+    s.set_stream(0)
+    r = s.minimize(max_trials=8)
+    assert r["status"] == ref["status"] and np.array_equal(r["trace"][:, :5], ref["trace"][:, :5])
+    assert s.timing()["n_graph_trials"] == 8  # (counted per device-controlled trial, graph or not)
+
+
+def test_executable_with_world_of_one_and_max_iter_stop(ba, gpu_ok, tmp_path):
+    """The executables' sharding switches with a world of one (RCCL communicator of one rank through the id file), and the LM
+    stop conditions other than flat-line reach the caller through the device-side control: max_iter -> MaxItersReached."""
+    import os
+    import subprocess
+    from conftest import DATA21, ROOT
+    exe = os.path.join(ROOT, "bundleadjustment_benchmarks_amd", "bin", "Bundle_Adjustment_Cholesky")
+    env = dict(os.environ, BA_MAX_TRIALS="4", BA_WORLD="1", BA_RANK="0", BA_COMM_FILE=str(tmp_path / "id"))
+    out = subprocess.run([exe, DATA21], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "LM finished with status: Running" in out.stdout and out.stdout.count("Accepted") == 4
+    p = ba.Problem.load_bal(DATA21)
+    s = ba.Solver(p, ba.CHOLESKY, ba.F64)
+    r = s.minimize(max_iter=3)
+    assert r["status"] == 3 and r["iterations"] == 4 and r["trials"] == 3  # the loop top of iteration 4 stops it (:243-248)
+    s2 = ba.Solver(p, ba.CHOLESKY, ba.F64)
+    r2 = s2.minimize(lambda_max=1e-30, max_trials=50)  # every accepted step leaves lambda > lambda_max: the first rejection ends the run
+    assert r2["status"] in (1, -1)
