@@ -186,8 +186,12 @@ def test_cfg5_full_size(ba, O, gpu_ok):
 def test_cfg3_f32_lm(ba, O, gpu_ok, prob39, kind):
     """Scalar = float on problem-39 under the QRKIT symbol (config 3: per-point QR + dense Householder QR of J2bot, 181 k x 351)
     and under QRCHOL: the accepted energies decrease, the first trial agrees with the fp32 oracle of the same symbol (energy
-    before 1e-5, test energy 2e-3, accept decision; the oracle's dense QR of that matrix takes ~1/2 minute per trial), and the
-    statistics after the run are finite."""
+    before 1e-5, accept decision, test energy 2e-3 -- or, when two fp32 solvers differ by more than that, the GPU is at least
+    as close as the fp32 oracle to the quad value of that trial, tests/golden/referee_problem39_qrchol.json trial 0; the
+    oracle's dense QR of that matrix takes ~1/2 minute per trial), and the statistics after the run are finite."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "referee_problem39_qrchol.json")) as f:
+        quad = json.load(f)["trials"][0]  # QRKIT and QRCHOL solve the same system from the same start and lambda0
     po = to_oracle(prob39)
     ro = O.minimize(kind, po, dtype=np.float32, max_trials=2)["trace"]
     s = ba.Solver(prob39, kind, ba.F32)
@@ -197,7 +201,9 @@ def test_cfg3_f32_lm(ba, O, gpu_ok, prob39, kind):
     assert len(acc) >= 3 and np.all(np.diff(acc[:, 2]) < 0)
     assert abs(tg[0, 2] - ro[0, 2]) < 1e-5 * ro[0, 2]
     assert tg[0, 1] == ro[0, 1] == 1
-    assert abs(tg[1, 2] - ro[1, 2]) < 2e-3 * ro[1, 2]  # f of row 1 = test energy of the first accepted step
+    assert abs(quad["lam"] - tg[0, 5]) < 1e-4 * quad["lam"] and abs(quad["energy_quad"] - tg[0, 2]) < 1e-5 * tg[0, 2]
+    eq = quad["e_test_quad"]  # f of row 1 = test energy of the first accepted step
+    assert abs(tg[1, 2] - ro[1, 2]) < 2e-3 * ro[1, 2] or abs(tg[1, 2] - eq) <= abs(ro[1, 2] - eq), (tg[1, 2], ro[1, 2], eq)
     st = s.stats()
     assert all(np.isfinite(st[k]) for k in ("mean_err", "inlier_mean_err", "objective"))
 
