@@ -138,12 +138,15 @@ __device__ __forceinline__ float ba_readlane(float v, int lane)
 
 template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], const T *__restrict__ Wp2 = nullptr, int p02 = 0);
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1]);
 template <typename T, int NB, bool TOLDS, bool STSC = false>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad, const T *__restrict__ Wp2 = nullptr, int p02 = 0);
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad);
 template <typename T, int NB>
 __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, int row0t, int col0t, T *S, const T *Wp, int quad);
+template <typename T, int NB>
+__device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, int pA, int row0, int col0, T *__restrict__ S,
+                                                const T *__restrict__ W1, const T *__restrict__ W2, T *__restrict__ As, T *__restrict__ Bs);
 
 // Panel step for block column p0: rows [p0, nrows), pivots [p0, min(p0 + 64, ncols)).
 //   S    : in place; on exit the block column holds L (strictly lower) and D (diagonal)
@@ -168,11 +171,12 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                               T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel,
-                                              const int *flags = nullptr, int epoch = 0, T *errw = nullptr)
+                                              T (&Ad)[NB][NB + 1], T (&Wl)[NB][NB + 1], const int *flags = nullptr, int epoch = 0,
+                                              T *errw = nullptr)
 {
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
-    __shared__ T Ad[NB][NB + 1]; // diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained
-    __shared__ T Wl[NB][NB + 1]; // W[row][col]
+    // Ad: diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained.  Wl: W[row][col].  Both are declared by
+    // the kernel: the macro-tile update of the same launch stages its operands in them (ba_update_macro).
     // Ys: unscaled sub-panel Y[col][row] (written in A2, read by the rank-16 updates, part of which run under the NEXT pivot
     // loop); Ts: per-wave scratch of the W tiles, kept in the strictly upper tiles of W's own image, which nobody reads.  ~79 KiB in total: two workgroups still fit a CU (the trailing-update
     // workgroups of the fused launch inherit the footprint).
@@ -573,6 +577,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++)
             xall[kk] = __hip_atomic_load(px + kk * (4 * (size_t)ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Waves w and w ^ 2 share their 16 rows: each reads ALL of X there and overwrites ITS two column tiles with L, in place.
+        // Every wave's X must have arrived before any wave stores.  (Found with two workgroups per CU, where the waves of a
+        // workgroup drift apart by microseconds: tile 3 of a row block was computed from tiles 1 and 2 of L instead of X.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         auto rowgemm = [&](auto tiles) { // tiles: the two column tiles of this wave (compile-time list)
             constexpr int NT = decltype(tiles)::n;
@@ -619,7 +628,8 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 {
     if (flags && blockIdx.x == 0) // hand-off flags of the fused steps that follow (k_ldlt_step<INL = true>): cleared per factorisation
         for (int i = threadIdx.x; i < nflags; i += 256) flags[i] = 0;
-    ba_panel_body<T, NB, false>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x);
+    __shared__ T Ad[NB][NB + 1], Wl[NB][NB + 1];
+    ba_panel_body<T, NB, false>(nrows, ncols, ld, p0, S, Wp, Winv, nullptr, blockIdx.x, gridDim.x, Ad, Wl);
 }
 
 // Fused step with look-ahead: ONE launch per block column p0 >= 64.
@@ -633,12 +643,16 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(int nrows, int ncols, int ld
 // stores), announce it in flags[row block] and leave; panel workgroup b picks its rows up just before its row GEMM.  They are
 // dispatched before the workgroups that wait for them, so the wait cannot starve them.  INL = false keeps that update
 // inside the panel workgroup (two helper waves, out of line), nq = 0.
-template <typename T, int NB, bool INL>
-__global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
-                                                   T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
-                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr,
-                                                   int upd_mode = 0, const T *__restrict__ Wprev2 = nullptr)
+// Macro-tile part of a launch (k_ldlt_step2): panels at columns pM and pM + 64 (Y in W1, W2) applied to the 128 x 128 tiles
+// rows base + 128 mi, columns base + 128 mj, mj <= mi (everything behind the block column that the launch itself factors).
+template <typename T> struct ba_macro_job { const T *W1, *W2; int pM, base, count; }; // base: first row / column of the tiles
+
+template <typename T, int NB, bool INL, bool MACRO>
+__device__ __forceinline__ void ba_step_body(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S, T *__restrict__ Wp,
+                                             const T *__restrict__ Wprev, T *__restrict__ Winv, int nq, int *__restrict__ flags,
+                                             T *__restrict__ errw, int upd_mode, int n64, const ba_macro_job<T> &mj)
 {
+    __shared__ T Ad[NB][NB + 1], Wl[NB][NB + 1];
     int bid = blockIdx.x;
     if (INL && bid < nq) {
         const int rown = p0 + NB + 64 * bid;
@@ -651,20 +665,30 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
     }
     if (INL) bid -= nq;
     if (bid < npanel) {
-        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, INL ? flags : nullptr, p0 / NB, errw);
+        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, Ad, Wl, INL ? flags : nullptr, p0 / NB, errw);
         return;
     }
-    // Trailing update by the workgroups behind the panel workgroups.  upd_mode 0: panel p - 1 on every tile of the set
-    // {(ti, tj): 1 <= tj <= ti, tj < ntc} (rows p0 + 64 ti, columns p0 + 64 tj).  Large matrices (config 5) alternate instead:
-    // upd_mode 1 (even steps): panel p - 1 on the NEXT block column only (tj = 1: the one the next step factors); upd_mode 2 (odd
-    // steps): panels p - 2 and p - 1 together on every tile (K = 128: the trailing matrix is read and written every second step).
-    // Measured at D = 9216: 9.4 against 10.0 ms -- the update is bound by the L2 traffic of its operands (one 8-byte load per lane
-    // and MFMA) as much as by the C tiles.  A 128 x 128 macro tile with the operands staged through LDS (4x less L2 traffic) was
-    // built and measured too: 10.5 ms -- next to the panel's 77 KiB its LDS leaves one workgroup per CU, and then nothing overlaps
-    // the 256 KiB of C traffic per tile (10 us) with its 14 us of MFMAs.  What it takes is that update as a kernel of its own
-    // (two workgroups per CU) running beside the panel launch; not built.
+    // Trailing update by the workgroups behind the panel workgroups.  First n64 workgroups with 64 x 64 tiles and panel p - 1 alone:
+    // upd_mode 0 on every tile of the set {(ti, tj): 1 <= tj <= ti, tj < ntc} (rows p0 + 64 ti, columns p0 + 64 tj), upd_mode 1 on
+    // the NEXT block column only (tj = 1: the one the next step factors).  Behind them (large matrices, k_ldlt_step2) the macro tiles
+    // of a PAIR of earlier panels: the trailing matrix is read and written once per two panels (K = 128).
     const int ntc = (ncols - p0 + 63) / 64;
     int u = bid - npanel, ti = 1, tj;
+    if (MACRO && u >= n64) {
+        u -= n64;
+        if (u >= mj.count) return;
+        const int base = mj.base, nmc = ((ncols - base + 63) / 64 + 1) / 2;
+        int mi = 0;
+        for (;; mi++) {
+            const int cnt = min(mi + 1, nmc);
+            if (u < cnt) break;
+            u -= cnt;
+        }
+        const int row0 = base + 128 * mi, col0 = base + 128 * u;
+        if (row0 >= nrows || col0 >= ncols) return;
+        ba_update_macro<T, NB>(nrows, ncols, ld, mj.pM, row0, col0, S, mj.W1, mj.W2, &Ad[0][0], &Wl[0][0]);
+        return;
+    }
     if (upd_mode == 1) { ti = 1 + u; tj = 1; }
     else {
         for (;; ti++) {
@@ -677,8 +701,29 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
     const int row0 = p0 + 64 * ti, col0 = p0 + 64 * tj;
     if (row0 >= nrows || col0 >= ncols) return;
     // (write-through stores: the 17 MB a launch writes leave the L2s while it runs, not in the release at its end)
-    if (upd_mode == 2 && Wprev2) ba_update_tile<T, NB, false, true>(ld, p0 - 2 * NB, row0, col0, ti == tj, S, Wprev2, nullptr, Wprev, p0 - NB);
-    else ba_update_tile<T, NB, false, true>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
+    ba_update_tile<T, NB, false, true>(ld, p0 - NB, row0, col0, ti == tj, S, Wprev, nullptr);
+}
+
+template <typename T, int NB, bool INL>
+__global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
+                                                   T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
+                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr)
+{
+    static_assert(INL, "the two-per-CU variant is k_ldlt_step2");
+    ba_step_body<T, NB, true, false>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, 0, 1 << 30, ba_macro_job<T>{});
+}
+
+// The two-workgroups-per-CU variant for update-bound sizes (no dynamic-LDS request): the same panel structure -- row workgroups in
+// front, two panel workgroups per row block -- and behind them the 64 x 64 tiles of one panel (upd_mode 0 / 1) and the macro tiles of
+// a pair of panels.  Built with -mllvm -amdgpu-mfma-vgpr-form (Makefile): with the accumulators of the macro-tile update in AGPRs
+// the kernel would need the panel's VGPRs PLUS 128 AGPRs (the unified file is split, not shared) and lose the second workgroup per
+// CU; tests/test_kernel_resources.py pins <= 256.
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void k_ldlt_step2(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S, T *__restrict__ Wp,
+                                                    const T *__restrict__ Wprev, T *__restrict__ Winv, int nq, int *__restrict__ flags,
+                                                    T *__restrict__ errw, int upd_mode, int n64, ba_macro_job<T> mj)
+{
+    ba_step_body<T, NB, true, true>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, upd_mode, n64, mj);
 }
 
 // Trailing update of one 64 x 64 tile with the 64-wide panel at block column p0: C_ij -= sum_k Y_ik L_jk.
@@ -689,11 +734,9 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
 // flight at once to cover the L2 latency.  LOWER: skip the strictly upper quadrant (diagonal tiles).
 // TOLDS: the C tile lives in the LDS image Cl[col][row] (64 x 65) instead of S (diagonal block inside the panel step).
 // STSC: the results leave with agent-scope (sc1, write-through) stores: another workgroup of the SAME launch reads them.
-// Wp2 != nullptr: a SECOND panel (block column p02, Y in Wp2) is applied in the same pass over the tile -- K = 128: the tile is
-// read and written once for two panels, which halves the traffic of the C tiles that bounds the update of a large matrix.
 template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad, const T *__restrict__ Wp2, int p02)
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], int quad)
 {
     const int lane = threadIdx.x & 63;
     const int qr = 32 * (quad >> 1), qc = 32 * (quad & 1);
@@ -713,27 +756,23 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
     // k-steps whose operands are in flight together: all sixteen for the diagonal block (latency: it is on the critical
     // path), eight for the trailing tiles (throughput: registers)
     constexpr int CH = TOLDS ? NB / 4 : ((NB / 4 < 8) ? NB / 4 : 8);
-    for (int pass = 0; pass < (Wp2 ? 2 : 1); pass++) { // (uniform)
-        const T *const Wq = pass ? Wp2 : Wp;
-        const int pq = pass ? p02 : p0;
 #pragma unroll
-        for (int half = 0; half < (NB / 4) / CH; half++) {
-            T a[CH][2], b[CH][2];
+    for (int half = 0; half < (NB / 4) / CH; half++) {
+        T a[CH][2], b[CH][2];
 #pragma unroll
-            for (int q = 0; q < CH; q++) {
-                const int kk = CH * half + q;
+        for (int q = 0; q < CH; q++) {
+            const int kk = CH * half + q;
 #pragma unroll
-                for (int t = 0; t < 2; t++) a[q][t] = S[(size_t)(pq + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k] (negated at use)
+            for (int t = 0; t < 2; t++) a[q][t] = S[(size_t)(p0 + 4 * kk + lk) * ld + col0 + 16 * t + li]; // A[j][k] = L[j][k] (negated at use)
 #pragma unroll
-                for (int u = 0; u < 2; u++) b[q][u] = Wq[(size_t)(4 * kk + lk) * ld + row0 + 16 * u + li];        // B[k][i] = Y[i][k]
-            }
-#pragma unroll
-            for (int q = 0; q < CH; q++)
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(-a[q][t], b[q][u], acc[t][u]);
+            for (int u = 0; u < 2; u++) b[q][u] = Wp[(size_t)(4 * kk + lk) * ld + row0 + 16 * u + li];        // B[k][i] = Y[i][k]
         }
+#pragma unroll
+        for (int q = 0; q < CH; q++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int u = 0; u < 2; u++) acc[t][u] = ba_mfma(-a[q][t], b[q][u], acc[t][u]);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -750,9 +789,104 @@ __device__ __forceinline__ void ba_update_quad(int ld, int p0, int row0t, int co
 
 template <typename T, int NB, bool TOLDS, bool STSC>
 __device__ __forceinline__ void ba_update_tile(int ld, int p0, int row0t, int col0t, bool lower, T *__restrict__ S,
-                                               const T *__restrict__ Wp, T (*Cl)[NB + 1], const T *__restrict__ Wp2, int p02)
+                                               const T *__restrict__ Wp, T (*Cl)[NB + 1])
 {
-    ba_update_quad<T, NB, TOLDS, STSC>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6, Wp2, p02); // wave w owns quadrant w
+    ba_update_quad<T, NB, TOLDS, STSC>(ld, p0, row0t, col0t, lower, S, Wp, Cl, threadIdx.x >> 6); // wave w owns quadrant w
+}
+
+// Trailing update of one 128 x 128 MACRO tile with TWO panels (block columns pA and pA + 64: K = 128), operands staged through
+// LDS -- the update of a large matrix (config 5).  The quadrant update above feeds every MFMA from one 8-byte L2 load per
+// lane; at D = 9216 that path, not the matrix cores, sets the pace (35 % of the fp64 rate).  Here a workgroup owns 128 rows x
+// 128 columns of C (wave w the 64 x 64 quadrant (w >> 1, w & 1): 4 x 4 accumulator tiles, 128 registers), and the operands
+// L[col0 + j][k] and Y[row0 + i][k] pass through LDS in stages of 16 values of k: per stage 2 x 16 KiB arrive with 16-byte
+// loads (one 1 KiB row of the column-major panel per wave and instruction), requested one stage ahead of the MFMAs that use them
+// and parked in the other half of the two LDS images the panel workgroups of the same launch use for the diagonal block (Ad, Wl:
+// 2 x 32.5 KiB), so the launch keeps its two workgroups per CU.  4x fewer operand bytes leave the L2 than with the quadrant
+// update, and a fragment is a conflict-free ds_read_b64: stage layout [k][row ^ 16 (k & 1)] -- the two values of k that one
+// half-wave reads land in different halves of the banks.
+// Waves whose quadrant lies outside the matrix or strictly above the diagonal skip their MFMAs and stores (they still help with
+// the staging); operand rows past the matrix are clamped (they feed skipped quadrants only).
+template <typename T> struct ba_vec2;
+template <> struct ba_vec2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct ba_vec2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <typename T, int NB>
+__device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, int pA, int row0, int col0, T *__restrict__ S,
+                                                const T *__restrict__ W1, const T *__restrict__ W2, T *__restrict__ As, T *__restrict__ Bs)
+{
+    typedef typename ba_vec2<T>::type v2;
+    constexpr int KS = 16, MT = 128, NST = 2 * NB / KS; // k per stage, macro tile, stages
+    static_assert(2 * KS * MT <= NB * (NB + 1), "two stages of one operand fit one LDS image");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wr = 64 * (wv >> 1), wc = 64 * (wv & 1);
+    const bool live = row0 + wr < nrows && col0 + wc < ncols && col0 + wc <= row0 + wr;
+    // staging: this thread moves, per stage and operand, 4 pairs: k = kq + 4 it (kq = tid >> 6), rows 2 (tid & 63), +1
+    const int sj = 2 * (tid & 63), kq = tid >> 6;
+    const int ja = min(col0 + sj, ld - 2), ib = min(row0 + sj, ld - 2);
+    v2 ga[4], gb[4];
+    auto request = [&](int st) {
+        const int panel = st / (NB / KS), k0 = (st % (NB / KS)) * KS; // first / second panel, k offset inside it
+        const T *const Lp = S + (size_t)(pA + NB * panel + k0 + kq) * ld + ja;
+        const T *const Yp = (panel ? W2 : W1) + (size_t)(k0 + kq) * ld + ib;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            ga[it] = *(const v2 *)(Lp + (size_t)(4 * it) * ld);
+            gb[it] = *(const v2 *)(Yp + (size_t)(4 * it) * ld);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int k = kq + 4 * it; // (k & 1) == (kq & 1)
+            const int o = buf * KS * MT + k * MT + (sj ^ (16 * (kq & 1)));
+            *(v2 *)(As + o) = ga[it];
+            *(v2 *)(Bs + o) = gb[it];
+        }
+    };
+    request(0);
+    typename ba_acc<T>::type acc[4][4];
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    acc[t][u][v] = S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * u + li];
+    }
+    park(0);
+    __syncthreads();
+    for (int st = 0; st < NST; st++) {
+        if (st + 1 < NST) request(st + 1);
+        if (live) {
+            const T *const Ab = As + (st & 1) * KS * MT, *const Bb = Bs + (st & 1) * KS * MT;
+#pragma unroll
+            for (int q = 0; q < KS / 4; q++) {
+                const int k = 4 * q + lk, sw = 16 * (lk & 1);
+                T a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) a[t] = Ab[k * MT + ((wc + 16 * t + li) ^ sw)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) b[u] = Bb[k * MT + ((wr + 16 * u + li) ^ sw)];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[t][u] = ba_mfma(-a[t], b[u], acc[t][u]);
+            }
+        }
+        if (st + 1 < NST) park((st + 1) & 1);
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    __hip_atomic_store(&S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * u + li], acc[t][u][v],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
@@ -1051,13 +1185,13 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
 {
     const int nblk = (ncols + NB - 1) / NB;
     const size_t wsz = (size_t)ld * NB;
-    const bool k128 = nblk >= 48; // update-bound sizes: two panels per pass over the trailing matrix (Wp: THREE panels, p % 3)
+    const bool k128 = nblk >= 48; // update-bound sizes: two panels per pass over the trailing matrix (Wp: FOUR panels, p % 4)
+    const int pair_min = getenv("BA_LDLT_PAIR_MIN") ? atoi(getenv("BA_LDLT_PAIR_MIN")) : 72;
     for (int p = 0; p < nblk; p++) {
         const int p0 = p * NB;
         const int below = nrows - (p0 + NB);
         const int npanel = below > 0 ? (below + 63) / 64 : 1;
-        T *wcur = Wp + (size_t)(k128 ? p % 3 : (p & 1)) * wsz, *wprev = Wp + (size_t)(k128 ? (p + 2) % 3 : ((p + 1) & 1)) * wsz;
-        const T *wprev2 = Wp + (size_t)((p + 1) % 3) * wsz; // (k128 only) panel p - 2
+        T *wcur = Wp + (size_t)(k128 ? p % 4 : (p & 1)) * wsz, *wprev = Wp + (size_t)(k128 ? (p + 3) % 4 : ((p + 1) & 1)) * wsz;
         // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
         // and keeps the previous panel's update off the diagonal block's path.
         const bool fused = nblk >= 2;
@@ -1078,17 +1212,38 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
             // sub-panel loop (one workgroup per CU by its dynamic-LDS request, so a panel workgroup never shares its CU
             // with an update workgroup).  Beyond, the update dominates: out-of-line variant, <= 256 registers + < 80 KiB
             // LDS = two per CU (tests/test_kernel_resources.py pins that).
-            if (nblk < 48) {
+            if (!k128) {
                 const int nq = below > 0 ? npanel : 0;      // workgroups that update the panel workgroups' rows (see k_ldlt_step)
                 const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
                 hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2, S, wcur,
                                    wprev, Winv + (size_t)p * NB * NB, nq, flags, errw);
             } else {
-                // step 1: the only panel there is; then even steps update the next block column alone, odd steps everything with two panels
-                const int mode = p == 1 ? 0 : (p & 1) ? 2 : 1;
-                const int ng = mode == 1 ? (ntc > 1 ? nt - 1 : 0) : nupd;
-                hipLaunchKernelGGL((k_ldlt_step<T, NB, false>), dim3(npanel + ng), dim3(256), 0, st, nrows, ncols, ld, p0, npanel, S, wcur,
-                                   wprev, Winv + (size_t)p * NB * NB, 0, (int *)nullptr, errw, mode, wprev2);
+                // The panels go in pairs (0, 1), (2, 3), ...: an odd step p applies panel p - 1 to the next block column alone (the
+                // one step p + 1 factors), the even step p + 1 applies the pair (p - 1, p) to everything from block column p + 2 on
+                // with 128 x 128 macro tiles: the trailing matrix is read and written once per two panels.  While fewer than
+                // pair_min block columns remain the update no longer sets the pace and a macro tile of a pair (20 us on its own)
+                // would outlast the panel (15 us): from the first odd step there, every step applies its predecessor's panel to
+                // everything with 64 x 64 tiles.  (Measured, D = 9216: 9.4 ms with the quadrant update and K = 128, 8.0 ms now;
+                // pair_min 40 / 56 / 72 / 88 / 104: 8.23 / 8.13 / 8.03 / 8.12 / 8.29 ms.  The same macro tiles with ONE panel in the
+                // tail are no faster than the quadrants, 1.80 against 1.75 ms at D = 4608: K = 64 moves 8 flop per byte of C and
+                // is bound by that traffic, ~5 TB/s, either way.)
+                const auto macro_count = [&](int base) {
+                    const int mr = ((nrows - base + 63) / 64 + 1) / 2, mc = ((ncols - base + 63) / 64 + 1) / 2;
+                    int n = 0;
+                    for (int mi = 0; mi < mr; mi++) n += mi + 1 < mc ? mi + 1 : mc;
+                    return base < ncols ? n : 0;
+                };
+                const int p_single = ((nblk - pair_min) | 1) > 1 ? ((nblk - pair_min) | 1) : 1; // first odd step of the single-panel tail
+                int mode = 0, n64 = 0;
+                ba_macro_job<T> mj{nullptr, nullptr, 0, 0, 0};
+                if (p >= p_single) n64 = nupd;
+                else if (p & 1) {
+                    mode = 1;
+                    n64 = ntc > 1 ? nt - 1 : 0;
+                } else mj = {Wp + (size_t)((p - 2) % 4) * wsz, wprev, p0 - 2 * NB, p0 + NB, macro_count(p0 + NB)};
+                const int nq = below > 0 ? npanel : 0, np2 = below > 0 ? 2 * npanel : 1;
+                hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64 + mj.count), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
+                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, mj);
             }
         }
     }

@@ -313,7 +313,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
-        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)3 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)4 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
         if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);

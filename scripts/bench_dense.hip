@@ -30,10 +30,10 @@ int main(int argc, char **argv)
     double *S, *Wp, *Winv, *x, *S0; int *flags;
     long long *stamps;
     CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
-    CK(hipMalloc(&Wp, sizeof(double) * (size_t)3 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
+    CK(hipMalloc(&Wp, sizeof(double) * (size_t)4 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
     CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)3 * ld * NB));
+    CK(hipMemset(Wp, 0, sizeof(double) * (size_t)4 * ld * NB));
     const int nflags = Dp / NB + 2; CK(hipMalloc(&flags, sizeof(int) * nflags)); CK(hipMemset(flags, 0, sizeof(int) * nflags));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
@@ -128,7 +128,7 @@ int main(int argc, char **argv)
             int nupd = 0;
             for (int ti = 1; ti < nt; ti++) nupd += std::min(ti, ntc - 1);
             if (p == 8) CK(hipEventRecord(f0, st));
-            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(3 * g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, 2 * g, S, wcur, wprev, Winv + (size_t)p * NB * NB, g, flags);
+            hipLaunchKernelGGL((k_ldlt_step<double, NB, true>), dim3(3 * g + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, 2 * g, S, wcur, wprev, Winv + (size_t)p * NB * NB, g, flags, (double *)nullptr);
             if (p == 8) CK(hipEventRecord(f1, st));
         }
         CK(hipStreamSynchronize(st));

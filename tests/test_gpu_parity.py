@@ -134,10 +134,13 @@ def test_lm_per_trial_injected_state_f64(ba, O, gpu_ok, prob21, kind):
         worst = max(worst, rel)
         # the step's sensitivity grows like 1/lambda (gauge directions of J'J are regularised by lambda only:
         # cond(J'J + lambda I) ~ 2.4e10 / lambda); measured deviation between two fp64 solvers ~ 1e-12 / lambda.
-        # Below lambda = 1e-9 the linear system is numerically singular (cond > 1e19) and the step is rounding noise
-        # in any implementation: no claim is made there.
+        # Below lambda = 1e-9 the linear system is numerically singular (cond > 1e19) and two fp64 steps differ by rounding
+        # noise: there the claim is made against the quad referee instead (test_gpu_referee.py, every trial of the run).
         if full[k][5] >= 1e-9:
-            assert rel < max(3e-9, 1e-11 / full[k][5]), (k, et, full[k][6])
+            w = quad[k]
+            assert w["lam"] == full[k][5] and abs(w["e_test_fp64"] - full[k][6]) <= 1e-14 * full[k][6]  # the same trial
+            closer = abs(et - w["e_test_quad"]) <= abs(full[k][6] - w["e_test_quad"])
+            assert rel < max(3e-9, 1e-11 / full[k][5]) or closer, (k, et, full[k][6], w["e_test_quad"])
         if full[k][5] >= 1e-5:
             assert (et < e) == bool(full[k][1])
             if full[k][1]:
