@@ -577,11 +577,6 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
 #pragma unroll
         for (int kk = 0; kk < NB / 4; kk++)
             xall[kk] = __hip_atomic_load(px + kk * (4 * (size_t)ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Waves w and w ^ 2 share their 16 rows: each reads ALL of X there and overwrites ITS two column tiles with L, in place.
-        // Every wave's X must have arrived before any wave stores.  (Found with two workgroups per CU, where the waves of a
-        // workgroup drift apart by microseconds: tile 3 of a row block was computed from tiles 1 and 2 of L instead of X.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         auto rowgemm = [&](auto tiles) { // tiles: the two column tiles of this wave (compile-time list)
             constexpr int NT = decltype(tiles)::n;
@@ -602,6 +597,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                     }
                 }
             }
+            // Waves w and w ^ 2 share their 16 rows: each reads ALL of X there and overwrites ITS two column tiles with L, in place.
+            // Every wave's X must have arrived (its MFMAs are done) before any wave stores.  (Found with two workgroups per CU,
+            // where the waves of a workgroup drift apart by microseconds: tile 3 of a row block was computed from tiles 1 and 2 of
+            // L instead of X.)
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < NT; u++)
 #pragma unroll
