@@ -130,3 +130,74 @@ double ref_energy(int N, int M, int K, const int *cam_idx, const int *pt_idx, co
     free(c); free(p); free(ms);
     return (double)e;
 }
+
+/* The Jacobian as the DERIVATIVE OF THE RESIDUAL FUNCTION, not as a restatement of the reference's hand-written dE_pos: central
+ * differences of ora_residuals through the reference's update_params (BAFunctor.h:299-342: additive, left-multiplication by the
+ * Rodrigues matrix of the increment for the rotation), in quad precision with one Richardson step -- (4 D(h/2) - D(h)) / 3,
+ * truncation O(h^4), rounding 1e-34 / h.  Pins ora_jacobian (and through it k_eval's Jacobian) to BAFunctor::E_pos independently of
+ * BAFunctor::dE_pos:181-297; the double finite differences of tests/test_oracle_math.py could only do that to 2e-3.
+ * The rotation increment uses the exponential map WITHOUT the reference's 1e-6 cut-off (MathUtils.h:74 leaves R untouched below
+ * it -- a property of tiny steps, not of the derivative): a pixel moves ~1e4 px per radian and the robust kernel bends on the
+ * scale tau = 0.5 px, so steps above the cut-off are far outside the linear range (measured: 9e-2 relative error at h = 2e-5).
+ * Steps: 1e-9 (rotation), 1e-8 x scale (others).  Jc_out: K x 18 (2 x 9 row-major), Jp_out: K x 6 -- ora_jacobian's layout. */
+static void ref_expmap(const S *om, S *R)
+{
+    const S t2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2], theta = sqrtq(t2);
+    const S J[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    const S c1 = theta > 0 ? sinq(theta) / theta : (S)1, c2 = theta > 0 ? ((S)1 - cosq(theta)) / t2 : (S)0.5;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            S a = 0;
+            for (int k = 0; k < 3; k++) a += J[i * 3 + k] * J[k * 3 + j];
+            R[i * 3 + j] = (i == j ? (S)1 : (S)0) + c1 * J[i * 3 + j] + c2 * a;
+        }
+}
+
+int ref_jacobian_fd(int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau,
+                    const double *cam15, const double *pts, double *Jc_out, double *Jp_out)
+{
+    (void)N; (void)M;
+    const int zero = 0;
+    for (int i = 0; i < K; i++) {
+        S cam[15], X[3], ms[2];
+        for (int k = 0; k < 15; k++) cam[k] = cam15[15 * (size_t)cam_idx[i] + k];
+        for (int k = 0; k < 3; k++) X[k] = pts[3 * (size_t)pt_idx[i] + k];
+        ms[0] = meas[2 * (size_t)i]; ms[1] = meas[2 * (size_t)i + 1];
+        for (int c = 0; c < 12; c++) { /* camera column c < 9: [T(3) omega(3) f k1 k2]; 9..11: the point */
+            S h = (c >= 3 && c < 6) ? (S)1e-9 : (S)1e-8;
+            if (c == 6) h *= 1000; /* focal length ~ 1e3 */
+            S D[2][2];
+            for (int lev = 0; lev < 2; lev++) {
+                const S hh = lev ? h / 2 : h;
+                S f2[2][2];
+                for (int sgn = 0; sgn < 2; sgn++) {
+                    const S d = sgn ? -hh : hh;
+                    S co[15], Xo[3] = {X[0], X[1], X[2]};
+                    for (int k = 0; k < 15; k++) co[k] = cam[k];
+                    if (c < 3) co[9 + c] += d;
+                    else if (c < 6) {
+                        S om[3] = {0, 0, 0}, dR[9];
+                        om[c - 3] = d;
+                        ref_expmap(om, dR);
+                        for (int r = 0; r < 3; r++)
+                            for (int q = 0; q < 3; q++) {
+                                S a = 0;
+                                for (int k = 0; k < 3; k++) a += dR[r * 3 + k] * cam[k * 3 + q];
+                                co[r * 3 + q] = a;
+                            }
+                    } else if (c < 9) co[12 + (c - 6)] += d;
+                    else Xo[c - 9] += d;
+                    (void)ora_residuals_f128(1, 1, 1, co, Xo, &zero, &zero, ms, (S)tau, f2[sgn]);
+                }
+                D[lev][0] = (f2[0][0] - f2[1][0]) / (2 * hh);
+                D[lev][1] = (f2[0][1] - f2[1][1]) / (2 * hh);
+            }
+            for (int r = 0; r < 2; r++) {
+                const S d = (4 * D[1][r] - D[0][r]) / 3;
+                if (c < 9) Jc_out[18 * (size_t)i + 9 * r + c] = (double)d;
+                else Jp_out[6 * (size_t)i + 3 * r + (c - 9)] = (double)d;
+            }
+        }
+    }
+    return 0;
+}

@@ -235,3 +235,17 @@ def referee_energy(p, cam15, pts, tau=0.5):
     cam15 = np.ascontiguousarray(cam15, np.float64).reshape(-1)
     pts = np.ascontiguousarray(pts, np.float64).reshape(-1)
     return float(referee().ref_energy(p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts)))
+
+
+def referee_jacobian_fd(p, cam15, pts, tau=0.5):
+    """(Jc [K,2,9], Jp [K,2,3]): the derivative of the RESIDUAL function through the retraction, by Richardson-extrapolated central
+    differences in quad precision (oracle/ba_referee.c: ref_jacobian_fd) -- independent of the hand-written Jacobian."""
+    cam15 = np.ascontiguousarray(cam15, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    Jc = np.zeros((p.K, 2, 9))
+    Jp = np.zeros((p.K, 2, 3))
+    rc = referee().ref_jacobian_fd(p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
+                                   _p(Jc), _p(Jp))
+    if rc:
+        raise RuntimeError("ref_jacobian_fd failed: %d" % rc)
+    return Jc, Jp

@@ -45,6 +45,22 @@ def test_linearize_matches_oracle(ba, O, gpu_ok, prob21, scalar, tol):
     assert relmax(cams_dev, cam) < (1e-15 if scalar == 0 else 1e-6)
 
 
+def test_gpu_jacobian_is_the_derivative_of_the_residual(ba, O, gpu_ok, prob21):
+    """k_eval's Jacobian against the derivative of the RESIDUAL function itself -- Richardson-extrapolated central differences in
+    quad precision through the reference's update_params (oracle/ba_referee.c: ref_jacobian_fd) -- on all 36 455 observations of
+    problem-21: an independent pin that does not go through the oracle's restatement of dE_pos (which shares its structure with
+    the kernel).  Per observation, relative to the largest entry of its 2 x 12 block."""
+    po = to_oracle(prob21)
+    cam = O.init_cams(po)
+    Fc, Fp = O.referee_jacobian_fd(po, cam, po.pts)
+    s = ba.Solver(prob21, ba.CHOLESKY, ba.F64)
+    s.linearize()
+    Jc, Jp = s.get(ba.GET_JC).reshape(-1, 2, 9), s.get(ba.GET_JP).reshape(-1, 2, 3)
+    sc = np.maximum(np.abs(Fc).max(axis=(1, 2)), np.abs(Fp).max(axis=(1, 2)))
+    assert (np.abs(Jc - Fc).max(axis=(1, 2)) / sc).max() < 1e-10
+    assert (np.abs(Jp - Fp).max(axis=(1, 2)) / sc).max() < 1e-10
+
+
 @pytest.mark.parametrize("kind", [2, 1, 3])
 def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     po = to_oracle(prob21)

@@ -54,6 +54,24 @@ def test_jacobian_finite_differences(O, small):
     assert worst < 2e-3, worst
 
 
+def test_jacobian_is_the_derivative_of_the_residual_in_quad(O, ba, small):
+    """The independent pin of ora_jacobian (dE_pos, BAFunctor.h:181-297): the derivative of ora_residuals (E_pos, :160-178) through
+    update_params (:299-342) by Richardson-extrapolated central differences in __float128 (oracle/ba_referee.c: ref_jacobian_fd),
+    on EVERY observation of a synthetic problem and of both BAL files the reference ships.  Measured: 5e-12 of the block's largest
+    entry (the double differences above cannot do better than 2e-3: the robust kernel bends on the scale of 0.5 px, a pixel moves
+    1e4 px per radian, and steps under the 1e-6 Rodrigues cut-off are not available in double)."""
+    from conftest import DATA21, DATA39
+    for p in (small, to_oracle(ba.Problem.load_bal(DATA21)), to_oracle(ba.Problem.load_bal(DATA39))):
+        cam = O.init_cams(p)
+        Jc, Jp = O.jacobian(p, cam, p.pts)
+        Jc, Jp = np.asarray(Jc).reshape(p.K, 2, 9), np.asarray(Jp).reshape(p.K, 2, 3)
+        Fc, Fp = O.referee_jacobian_fd(p, cam, p.pts)
+        sc = np.maximum(np.abs(Fc).max(axis=(1, 2)), np.abs(Fp).max(axis=(1, 2)))
+        assert (np.abs(Jc - Fc).max(axis=(1, 2)) / sc).max() < 1e-10
+        assert (np.abs(Jp - Fp).max(axis=(1, 2)) / sc).max() < 1e-10
+
+
+
 @pytest.mark.parametrize("kind", [2, 1, 0, 3])
 def test_step_solves_normal_equations(O, small, kind):
     """All four symbols solve (J'J + lambda I) dx = -J'r (QR of [J; sqrt(lambda) I] == normal equations)."""
