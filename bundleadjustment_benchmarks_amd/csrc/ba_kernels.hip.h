@@ -203,10 +203,16 @@ __global__ __launch_bounds__(256) void k_stats(int K, int N, int Ml, const T *__
 struct ba_red_job { const void *src; int n; int op; int dst; }; // op 0 sum, 1 max
 struct ba_red_jobs { ba_red_job j[8]; };
 
-template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal, const int *__restrict__ go = nullptr)
+// stamp != nullptr: block 0 leaves the device's wall clock there when it is done (also when `go` turns the launch into a no-op):
+// the last kernel of an LM iteration's control segment marks its end for k_lm_control's per-trial timing.
+template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal, const int *__restrict__ go = nullptr,
+                                                                              long long *__restrict__ stamp = nullptr)
 {
     __shared__ T red[4];
-    if (go && *go == 0) return;
+    if (go && *go == 0) {
+        if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)wall_clock64();
+        return;
+    }
     const ba_red_job jb = jobs.j[blockIdx.x];
     const T *src = (const T *)jb.src;
     T a = 0;
@@ -217,7 +223,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba
         for (int k = threadIdx.x; k < jb.n; k += 256) a = tmax(a, src[k]);
         a = block_reduce<T, true>(a, red);
     }
-    if (threadIdx.x == 0) scal[jb.dst] = a;
+    if (threadIdx.x == 0) {
+        scal[jb.dst] = a;
+        if (stamp && blockIdx.x == 0) *stamp = (long long)wall_clock64();
+    }
 }
 
 // ---- K3 (point part): U0_j = sum B^T B, g_p = -sum B^T r per point, once per outer iteration ------------------
@@ -999,8 +1008,15 @@ template <typename T> struct ba_lm_dev {
     int go;       // the last trial was accepted and x = xTest is to happen: k_commit and the linearisation behind it run
     int fresh;    // the linearisation at x has been redone since `energy` was set: take it from scal[SC energy slot]
     int max_iter, max_fun_ev, max_trials, deverr;
+    // per-trial device times without events between the launches (the whole iteration is ONE graph): wall_clock64() at the start of
+    // k_lm_control = the end of the trial (t_ctl), and at the end of the control segment's last kernel (t_end, k_reduce_scalars)
+    long long t_ctl, t_end;
+    int timed;   // t_ctl / t_end describe the iteration just before this one (not the host-synchronous first linearisation)
+    int prev_go; // ... and that iteration linearised
 };
-struct ba_lm_row { double iter, accepted, f, rho, lambda, lambda_used, e_test, dx_norm; };
+// trial_ticks: t_ctl - previous t_end (elimination ... test energy); ctl_ticks_prev: the control segment (control, x = xTest,
+// linearisation) that preceded this trial; both < 0 when unknown
+struct ba_lm_row { double iter, accepted, f, rho, lambda, lambda_used, e_test, dx_norm, trial_ticks, ctl_ticks_prev, prev_go; };
 struct ba_lm_host { int done, stop, status, pad; ba_lm_row rows[BA_LM_RING]; };
 struct ba_lm_slots { int energy, etest, rho_p, rho_c, dn_p, dn_c, lambda, err; }; // indices into scal[]
 
@@ -1008,6 +1024,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_dev<T> *__restrict__ lm, ba_lm_host *__restrict__ host, ba_lm_slots sl)
 {
     if (threadIdx.x != 0) return;
+    const long long now = (long long)wall_clock64();
     ba_lm_dev<T> s = *lm;
     if (s.stop) { // a trial enqueued behind the end of the run: it changes nothing
         if (s.go) lm->go = 0;
@@ -1025,6 +1042,11 @@ __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_d
     const int t = s.trials++;
     const T lam_used = s.lambda;
     ba_lm_row row;
+    row.trial_ticks = s.timed ? (double)(now - s.t_end) : -1.0;
+    row.ctl_ticks_prev = s.timed ? (double)(s.t_end - s.t_ctl) : -1.0;
+    row.prev_go = s.prev_go;
+    s.t_ctl = now;
+    s.timed = 1;
     row.iter = s.iter; row.f = (double)s.energy; row.lambda_used = (double)lam_used; row.e_test = (double)e_test; row.dx_norm = sqrt((double)dn);
     int go = 0;
     if (scal[sl.err] != (T)0) { // a hand-off wait ran out inside this trial (ba_dense.hip.h): the step is garbage, stop loudly
@@ -1066,6 +1088,7 @@ __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_d
     }
     if (!s.stop && s.max_trials > 0 && s.trials >= s.max_trials) { s.stop = 1; s.status = -1; } // the max_trials extension: Running
     s.go = go;
+    s.prev_go = go;
     scal[sl.lambda] = s.lambda;
     *lm = s;
     host->rows[t % BA_LM_RING] = row;

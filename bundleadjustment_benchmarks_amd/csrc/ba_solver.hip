@@ -135,7 +135,8 @@ template <typename T> struct Solver final : SolverBase {
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
     T *h_lam = nullptr; // pinned staging word for lambda
-    // one LM trial as hipGraphs: world == 1: g_trial (elimination ... test energy), g_ctl (control, x = xTest, linearisation);
+    // one LM iteration as hipGraphs: world == 1: g_trial = elimination ... test energy, control, x = xTest, linearisation in ONE graph
+    // (two graphs with events between them left 18 + 27 us of idle GPU per iteration at config 4: 0.872 -> 0.852 ms);
     // sharded: g_a (elimination, assembly, pack) | all-reduce | g_b (unpack ... test energy) | all-reduce | g_ctl
     hipGraphExec_t g_trial = nullptr, g_a = nullptr, g_b = nullptr, g_ctl = nullptr;
     bool use_graph = true;
@@ -145,6 +146,7 @@ template <typename T> struct Solver final : SolverBase {
     int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
     bool have_step = false;
     int num_cus = 256; // of the device the solver lives on
+    double wall_khz = 1e5;
 
     ~Solver() override
     {
@@ -190,6 +192,8 @@ template <typename T> struct Solver final : SolverBase {
             hipDeviceProp_t pr;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
                 num_cus = pr.multiProcessorCount;
+            int khz = 0; // rate of wall_clock64(), the constant-frequency counter behind the per-trial device times (100 MHz on gfx950)
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) wall_khz = khz;
         }
 #define UP(buf, vec) if ((rc = buf.upload(vec))) return rc
         UP(d_obs_cam, sx.obs_cam); UP(d_obs_pt, sx.obs_pt); UP(d_pt_ptr, sx.pt_ptr); UP(d_pair_hi, sx.pair_hi);
@@ -435,7 +439,7 @@ template <typename T> struct Solver final : SolverBase {
             jobs.j[nj++] = {d_part_pm.p, gM, 1, SC_DMAX_P};
             jobs.j[nj++] = {tmp, D, 1, SC_DMAX_C};
         }
-        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p, go);
+        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(nj), dim3(256), 0, st, jobs, d_scal.p, go, &d_lm.p->t_end);
         if (!go) HIPCHK(hipEventRecord(ev[EV_L1], st));
         have_step = false;
         return BA_OK;
@@ -792,6 +796,7 @@ template <typename T> struct Solver final : SolverBase {
         return BA_OK;
     }
     int launch_seg_ab() { int rc = launch_seg_a(); return rc ? rc : launch_seg_b(); }
+    int launch_seg_iter() { int rc = launch_seg_ab(); return rc ? rc : launch_seg_ctl(); }
 
     // one segment: replay its graph, or (legacy stream, BA_NO_GRAPH, sharding through a host callback) launch it directly
     int run_seg(hipGraphExec_t *g, int (Solver::*seg)(), bool graphs)
@@ -807,13 +812,10 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         EvSlot &e = ring[slot];
+        if (!sharded()) // ONE graph per LM iteration and no event between the launches: the times come from the device's wall clock
+            return run_seg(&g_trial, &Solver::launch_seg_iter, graphs);
         HIPCHK(hipEventRecord(e.e[0], st));
-        if (!sharded()) {
-            if ((rc = run_seg(&g_trial, &Solver::launch_seg_ab, graphs))) return rc;
-            HIPCHK(hipEventRecord(e.e[1], st));
-            HIPCHK(hipEventRecord(e.e[2], st));
-            HIPCHK(hipEventRecord(e.e[3], st));
-        } else {
+        {
             if ((rc = run_seg(&g_a, &Solver::launch_seg_a, graphs))) return rc;
             HIPCHK(hipEventRecord(e.e[1], st));
             if ((rc = allreduce(d_pack.p, pack_count() + 1, 0))) return rc; // reduced camera system + rhs + g_c + energy tail
@@ -889,12 +891,17 @@ template <typename T> struct Solver final : SolverBase {
                     const double el = std::chrono::duration<double>(tnow - tlast).count();
                     tlast = tnow;
                     acc_of[consumed % RING_EV] = r.accepted != 0;
+                    if (!sharded()) { // device wall-clock stamps (k_lm_control): no events sit between the launches of an iteration
+                        tm.n_graph_trials++;
+                        if (r.trial_ticks >= 0) { tm.trial_ms += r.trial_ticks / wall_khz; tm.n_trials++; } // (not the first: host time sits in front of it)
+                        if (r.ctl_ticks_prev >= 0 && r.prev_go != 0) { tm.linearize_ms += r.ctl_ticks_prev / wall_khz; tm.n_linearize++; }
+                    }
                     if (cb) cb(user, (int)r.iter, (int)r.accepted, r.f, r.rho, r.lambda, el);
                     if (talk) // outputIter, BacktrackLevMarqQRChol.h:84-93 (f is the energy BEFORE the step)
                         printf("%5d%15s%15g%15g%15g%14gs\n", (int)r.iter, r.accepted != 0 ? "Accepted" : "Rejected", r.f, r.rho, r.lambda, el);
                     consumed++;
                 }
-                while (harvested + 1 < consumed) { harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; } // (its events are complete)
+                while (harvested + 1 < consumed) { if (sharded()) harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; } // (its events are complete)
                 return done;
             };
             auto tprog = std::chrono::steady_clock::now(); // last time the device made progress (a trial finished)
@@ -921,7 +928,7 @@ template <typename T> struct Solver final : SolverBase {
             const hipError_t es = hipStreamSynchronize(st);
             if (es != hipSuccess) { fprintf(stderr, "ba_mi355x: %s\n", hipGetErrorString(es)); return BA_ERR_HIP; }
             drain();
-            while (harvested < consumed) { harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; }
+            while (harvested < consumed) { if (sharded()) harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; }
             if (rc) return rc;
             HIPCHK(hipMemcpy(&h, d_lm.p, sizeof h, hipMemcpyDeviceToHost));
             if (h.fresh) { // stopped (max_trials) right behind an accepted step: the energy of the linearisation that followed it
@@ -941,7 +948,7 @@ template <typename T> struct Solver final : SolverBase {
             out->status = h.status; out->iterations = h.iter; out->trials = h.trials; out->fun_evals = h.fun_evals;
             out->energy = (double)h.energy; out->lambda = (double)h.lambda;
             out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tbeg).count();
-            const long long nt = tm.n_graph_trials - tm0.n_graph_trials, nl = tm.n_linearize - tm0.n_linearize;
+            const long long nt = tm.n_trials - tm0.n_trials, nl = tm.n_linearize - tm0.n_linearize; // (the timed ones)
             out->schur_ms = nt ? (tm.trial_ms - tm0.trial_ms) / nt : 0.0; // whole trial incl. the test-energy evaluation and the all-reduces
             out->linearize_ms = nl ? (tm.linearize_ms - tm0.linearize_ms) / nl : 0.0;
         }
