@@ -71,11 +71,19 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                                               const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
                                               T *__restrict__ Jp, T *__restrict__ JcA /* [K][20] AoS copy: A (18), r (2) */,
-                                              T *__restrict__ partial, const int *__restrict__ go = nullptr)
+                                              T *__restrict__ partial, const int *__restrict__ go = nullptr,
+                                              T *__restrict__ commit_cam = nullptr, T *__restrict__ commit_pts = nullptr)
 {
     __shared__ T red[4];
     if (go && *go == 0) return; // device-side LM control: the trial in front of this linearisation was rejected (uniform)
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (commit_cam) { // x = xTest (BacktrackLevMarqQRChol.h:428) rides on the linearisation at xTest: cam / pts ARE xTest here
+        const int ncam = 15 * N, ntot = ncam + 3 * Ml;
+        for (int q = i; q < ntot; q += gridDim.x * 256) {
+            if (q < ncam) commit_cam[q] = cam[q];
+            else commit_pts[q - ncam] = pts[q - ncam];
+        }
+    }
     T e2 = 0;
     if (i < K) {
         const int ci = obs_cam[i], pj = obs_pt[i];
@@ -205,15 +213,9 @@ struct ba_red_jobs { ba_red_job j[8]; };
 
 // stamp != nullptr: block 0 leaves the device's wall clock there when it is done (also when `go` turns the launch into a no-op):
 // the last kernel of an LM iteration's control segment marks its end for k_lm_control's per-trial timing.
-template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal, const int *__restrict__ go = nullptr,
-                                                                              long long *__restrict__ stamp = nullptr)
+// one job by one 256-thread block: fixed order (thread k, k + 256, ...; tree inside a wave; waves in index order)
+template <typename T> __device__ __forceinline__ void ba_reduce_job(const ba_red_job &jb, T *__restrict__ scal, T *red)
 {
-    __shared__ T red[4];
-    if (go && *go == 0) {
-        if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)wall_clock64();
-        return;
-    }
-    const ba_red_job jb = jobs.j[blockIdx.x];
     const T *src = (const T *)jb.src;
     T a = 0;
     if (jb.op == 0) {
@@ -223,10 +225,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba
         for (int k = threadIdx.x; k < jb.n; k += 256) a = tmax(a, src[k]);
         a = block_reduce<T, true>(a, red);
     }
-    if (threadIdx.x == 0) {
-        scal[jb.dst] = a;
-        if (stamp && blockIdx.x == 0) *stamp = (long long)wall_clock64();
-    }
+    if (threadIdx.x == 0) scal[jb.dst] = a;
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba_red_jobs jobs, T *__restrict__ scal, const int *__restrict__ go = nullptr,
+                                                                              long long *__restrict__ stamp = nullptr)
+{
+    __shared__ T red[4];
+    if (!(go && *go == 0)) ba_reduce_job<T>(jobs.j[blockIdx.x], scal, red);
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)wall_clock64();
 }
 
 // ---- K3 (point part): U0_j = sum B^T B, g_p = -sum B^T r per point, once per outer iteration ------------------
@@ -315,13 +322,23 @@ __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int
     }
 }
 
+// tail.src != nullptr: one more block at the end of the grid sums the energy partials of k_eval (the reduction that closes a
+// linearisation; a launch of its own otherwise) and leaves the wall-clock stamp that ends the control segment (k_lm_control).
 template <typename T>
-__global__ __launch_bounds__(192) void k_cam_gram_reduce(int N, const int *__restrict__ cam_dchunk_ptr,
+__global__ __launch_bounds__(256) void k_cam_gram_reduce(int N, const int *__restrict__ cam_dchunk_ptr,
                                                          const T *__restrict__ dslab, T *__restrict__ V /* [N][81] */,
-                                                         T *__restrict__ gc /* [9N] */, const int *__restrict__ go = nullptr)
+                                                         T *__restrict__ gc /* [9N] */, const int *__restrict__ go = nullptr,
+                                                         ba_red_job tail = ba_red_job{nullptr, 0, 0, 0}, T *__restrict__ scal = nullptr,
+                                                         long long *__restrict__ stamp = nullptr)
 {
+    __shared__ T red[4];
+    if (tail.src && blockIdx.x == gridDim.x - 1) {
+        if (!(go && *go == 0)) ba_reduce_job<T>(tail, scal, red);
+        if (stamp && threadIdx.x == 0) *stamp = (long long)wall_clock64();
+        return;
+    }
     if (go && *go == 0) return;
-    const int idx = blockIdx.x * 192 + threadIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     const int a = idx / BA_SLAB, e = idx - a * BA_SLAB;
     if (a >= N || e >= 54) return;
     // four interleaved partial sums (fixed order) keep four loads in flight
@@ -883,16 +900,28 @@ __global__ __launch_bounds__(256) void k_pack_lower(int Dp, int ld, T *__restric
 // ---- K7 + K8 (points): back-substitution, point retraction, rho terms ----------------------------------------
 // dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i]))  (src/Eigen_ext/BacktrackLevMarqQRChol.h:343-360);
 // x_test = x + dx_p (src/Optimization/BAFunctor.h:335-338); partial sums of dx^T (lambda dx + JtRes) (:375) and |dx|^2.
+struct ba_cam_retract_args { int N; const void *cam, *dxc, *gc; void *cam_test, *scal; int dst; };
+template <typename T>
+__device__ __forceinline__ void ba_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc, const T *__restrict__ gc,
+                                                const T *__restrict__ lam, T *__restrict__ cam_test, T *__restrict__ scal, int dst, T *red);
+
+// cr.N > 0: one more block at the end of the grid retracts the cameras (K8, below: a launch of its own otherwise); npart = the
+// number of point blocks = the row length of partial[2][npart].
 template <typename T, int LPP>
 __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__ pt_ptr, const int *__restrict__ obs_cam,
                                                  const T *__restrict__ rec, const T *__restrict__ dinv, const T *__restrict__ tvec,
                                                  const T *__restrict__ tri, const T *__restrict__ dxc, const T *__restrict__ gp,
                                                  const T *__restrict__ pts, const T *__restrict__ lam, T *__restrict__ dxp, T *__restrict__ pts_test,
-                                                 T *__restrict__ partial /* [2][grid] */, const int *__restrict__ pperm /* column permutation of the point's 3x3 block */)
+                                                 T *__restrict__ partial /* [2][npart] */, const int *__restrict__ pperm /* column permutation of the point's 3x3 block */,
+                                                 int npart, ba_cam_retract_args cr)
 {
     // LPP lanes per point: each lane forms Z_i^T dx_c for its observations (i = g, g + LPP, ...), a butterfly sum over
     // the group gives the point's 3-vector, lane 0 of the group finishes the 3x3 triangular solve.
     __shared__ T red[4];
+    if (cr.N > 0 && (int)blockIdx.x == npart) {
+        ba_retract_cams<T>(cr.N, (const T *)cr.cam, (const T *)cr.dxc, (const T *)cr.gc, lam, (T *)cr.cam_test, (T *)cr.scal, cr.dst, red);
+        return;
+    }
     const int gid = (blockIdx.x * 256 + threadIdx.x) / LPP, lg = threadIdx.x % LPP;
     const int j = gid < Ml ? gid : Ml - 1;
     const int b = pt_ptr[j], e = pt_ptr[j + 1];
@@ -932,18 +961,17 @@ __global__ __launch_bounds__(256) void k_backsub(int Ml, const int *__restrict__
     }
     rho = block_reduce<T, false>(rho, red);
     dn = block_reduce<T, false>(dn, red);
-    if (threadIdx.x == 0) { partial[blockIdx.x] = rho; partial[gridDim.x + blockIdx.x] = dn; }
+    if (threadIdx.x == 0) { partial[blockIdx.x] = rho; partial[npart + blockIdx.x] = dn; }
 }
 
 // ---- K8 (cameras): BAFunctor::update_params (src/Optimization/BAFunctor.h:311-332) -----------------------------
 // T += dT; R <- Rodrigues(d omega) R (identity when |d omega| <= 1e-6, src/MathUtils.h:66-82); f, k1, k2 += .
 // Single block (N <= a few thousand cameras); also the camera part of the rho / |dx|^2 sums -> scal[dst..dst+1].
 template <typename T>
-__global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc,
-                                                      const T *__restrict__ gc, const T *__restrict__ lam, T *__restrict__ cam_test,
-                                                      T *__restrict__ scal, int dst)
+__device__ __forceinline__ void ba_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc,
+                                                const T *__restrict__ gc, const T *__restrict__ lam, T *__restrict__ cam_test,
+                                                T *__restrict__ scal, int dst, T *red)
 {
-    __shared__ T red[4];
     const T lambda = *lam;
     T rho = 0, dn = 0;
     for (int a = threadIdx.x; a < N; a += 256) {
@@ -990,6 +1018,15 @@ __global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict
     rho = block_reduce<T, false>(rho, red);
     dn = block_reduce<T, false>(dn, red);
     if (threadIdx.x == 0) { scal[dst] = rho; scal[dst + 1] = dn; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_retract_cams(int N, const T *__restrict__ cam, const T *__restrict__ dxc,
+                                                      const T *__restrict__ gc, const T *__restrict__ lam, T *__restrict__ cam_test,
+                                                      T *__restrict__ scal, int dst)
+{
+    __shared__ T red[4];
+    ba_retract_cams<T>(N, cam, dxc, gc, lam, cam_test, scal, dst, red);
 }
 
 // ---- a-8: step control on the device ---------------------------------------------------------------------------

@@ -377,25 +377,28 @@ template <typename T> struct Solver final : SolverBase {
     double ev_ms(int a, int b) { return ev_ms(ev[a], ev[b]); }
 
     // which: 0 = x, 1 = xTest
-    void launch_eval(bool jac, int which, const int *go = nullptr)
+    // commit (with jac, which = 1): the linearisation AT xTest also performs x = xTest (k_commit's copy rides on k_eval)
+    void launch_eval(bool jac, int which, const int *go = nullptr, bool commit = false)
     {
         const T tau2 = tau * tau;
         if (jac)
             hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go);
+                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go,
+                               commit ? d_cam[0].p : (T *)nullptr, commit ? d_pts[0].p : (T *)nullptr);
         else
             hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
                                d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p, go);
     }
 
-    void launch_grad(const int *go = nullptr)
+    // tail: the energy reduction that closes the linearisation, as one more block of the last launch (+ the control segment's end stamp)
+    void launch_grad(const int *go = nullptr, const ba_red_job *tail = nullptr)
     {
         hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p, d_part_pm.p, go);
         if (sx.ndchunks > 0)
             hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
                                d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
-        hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 191) / 192), dim3(192), 0, st, N, d_cam_dchunk_ptr.p,
-                           d_dslab.p, d_V.p, d_gc.p, go);
+        hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 255) / 256 + (tail ? 1 : 0)), dim3(256), 0, st, N, d_cam_dchunk_ptr.p,
+                           d_dslab.p, d_V.p, d_gc.p, go, tail ? *tail : ba_red_job{nullptr, 0, 0, 0}, d_scal.p, tail ? &d_lm.p->t_end : (long long *)nullptr);
     }
 
     // m_functor(x, r); energy; m_functor.df(x, J); JtRes; column norms (BacktrackLevMarqQRChol.h:257-280), host-synchronous
@@ -424,13 +427,17 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         if (!go) HIPCHK(hipEventRecord(ev[EV_L0], st));
-        launch_eval(true, 0, go);
-        launch_grad(go);
-        if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
-            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go);
+        // behind a trial (go != nullptr): the linearisation is AT xTest and carries x = xTest along (no k_commit launch), and the
+        // energy sum rides on the last launch of launch_grad (no k_reduce_scalars launch) unless MOREQR's outer QR follows it
         ba_red_jobs jobs{};
         int nj = 0;
         jobs.j[nj++] = {d_part_e.p, gK, 0, sharded() ? SC_ELOC : SC_ENERGY};
+        const bool tail = go != nullptr && !want_dmax && kind != BA_MOREQR;
+        launch_eval(true, go ? 1 : 0, go, go != nullptr);
+        launch_grad(go, tail ? &jobs.j[0] : nullptr);
+        if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
+            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go);
+        if (tail) { have_step = false; return BA_OK; }
         if (want_dmax) {
             // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
             T *tmp = d_dxc.p;
@@ -529,11 +536,13 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_backsub_retract()
     {
-        if (Ml > 0) // (an empty shard keeps the zero partial sums written at creation)
-        hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
-                           d_tri.p, d_dxc.p, d_gp.p, d_pts[0].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1].p, d_part_bs.p, d_pperm.p);
-        hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[0].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
-                           d_cam[1].p, d_scal.p, (int)SC_RHO_C);
+        if (Ml > 0) { // the camera retraction rides as one more block at the end of the grid
+            const ba_cam_retract_args cr{N, d_cam[0].p, d_dxc.p, d_gcg.p, d_cam[1].p, d_scal.p, (int)SC_RHO_C};
+            hipLaunchKernelGGL((k_backsub<T, 8>), dim3(gB + 1), dim3(256), 0, st, Ml, d_pt_ptr.p, d_obs_cam.p, d_rec.p, d_dinv.p, d_tvec.p,
+                               d_tri.p, d_dxc.p, d_gp.p, d_pts[0].p, d_scal.p + SC_LAMBDA, d_dxp.p, d_pts[1].p, d_part_bs.p, d_pperm.p, gB, cr);
+        } else // (an empty shard keeps the zero partial sums written at creation)
+            hipLaunchKernelGGL((k_retract_cams<T>), dim3(1), dim3(256), 0, st, N, d_cam[0].p, d_dxc.p, d_gcg.p, d_scal.p + SC_LAMBDA,
+                               d_cam[1].p, d_scal.p, (int)SC_RHO_C);
     }
 
     void launch_test_energy()
@@ -587,10 +596,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         ba_lm_slots sl{sharded() ? SC_ENERGY : SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR};
         hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(64), 0, st, d_scal.p, d_lm.p, d_log, sl);
-        const int *go = &d_lm.p->go;
-        const int ncam = 15 * N, npts = 3 * Ml;
-        hipLaunchKernelGGL((k_commit<T>), dim3((ncam + npts + 255) / 256), dim3(256), 0, st, ncam, npts, d_cam[1].p, d_pts[1].p, d_cam[0].p, d_pts[0].p, go);
-        return linearize_enqueue(false, go);
+        return linearize_enqueue(false, &d_lm.p->go); // (x = xTest happens inside its first kernel)
     }
 
     // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375): the step-level
