@@ -11,14 +11,15 @@
 // oracle/ba_oracle_impl.h: solve_reduced_qr).
 //
 // The QR is blocked by 32-column panels; a panel is factored as a TSQR tree so that no reflector ever needs a grid-wide
-// reduction: level 1 cuts the rows into chunks of CH (1024 fp32 / 512 fp64) that one workgroup factors in LDS (Householder,
+// reduction: level 1 cuts the rows into chunks of CH (256 fp32 / 128 fp64) that ONE WAVEFRONT factors in registers (Householder,
 // column by column, reflectors stored in place below the diagonal of the chunk, the chunk's 32 x 32 R on its top rows); level
 // L + 1 stacks the R's of NSB = CH / 32 level-L chunks (their top rows, in place: row stride CH * NSB^(L-1)) and factors the
 // stack the same way -- its reflectors only have entries where the stacked triangles had them, so they fit in the triangles
 // they annihilate and the lower-level reflectors underneath stay intact.  The trailing columns (and the right-hand side, which
-// rides along as column D) receive the chunk reflectors level by level: one workgroup per (chunk, 32 columns) holds the tile in
-// LDS and applies the 32 reflectors one after the other (fp32 matrix cores run at the vector rate on this chip, and the
-// tile never leaves LDS, so the compact-WY form would buy nothing here).
+// rides along as column D) receive the chunk reflectors level by level: one wavefront per (chunk, 32 columns) holds the tile in
+// registers and applies the 32 reflectors one after the other.  No LDS tile and no barrier anywhere: round 2's first version
+// (one workgroup per 1024-row chunk, tile in LDS, five barriers per reflector) spent 8 - 11 us per reflector waiting on LDS
+// round trips and ran 26 ms per trial at config 3.
 #ifndef BA_QR_HIP_H
 #define BA_QR_HIP_H
 
@@ -26,9 +27,17 @@
 
 #define BA_QR_PB 32 /* panel width = rows of a sub-block */
 
+__device__ __forceinline__ float ba_readlane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ double ba_readlane63(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
 template <typename T> struct ba_qr_cfg {
-    static constexpr int NSB = sizeof(T) == 4 ? 32 : 16; // sub-blocks (of 32 rows) per chunk
-    static constexpr int CH = BA_QR_PB * NSB;            // rows per chunk: 128 KiB of LDS for a CH x 32 tile
+    static constexpr int NSB = sizeof(T) == 4 ? 8 : 4; // sub-blocks (of 32 rows) per chunk
+    static constexpr int CH = BA_QR_PB * NSB;          // rows per chunk = 64 lanes x 4 (fp32) / 2 (fp64) rows: a CH x 32 tile is 128 registers per lane
 };
 
 // global row of local row l of chunk g: sub-block s = l / 32 starts at row0 + (g NSB + s) stride, stride = 32 at level 1
@@ -95,155 +104,150 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
     }
 }
 
-// ---- one chunk of a TSQR level: Householder QR of its rows of the panel, in LDS -----------------------------------------
-// level 1: the chunk's rows are dense; level > 1: every sub-block is an upper triangle (the R of a lower-level chunk) -- entries
-// below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
+// ---- one chunk of a TSQR level: Householder QR of its rows of the panel, one WAVEFRONT per chunk, in registers ---------------
+// Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them) and all 32 panel columns: no LDS tile, no barrier.
+// Step j works on the column at register position 0 (norm below the pivot by a wave reduction, the scalars redundantly in every
+// lane, the reflector v in RPL registers), updates the positions behind it -- one wave reduction per column for v . a_c --,
+// retires position 0 to memory (R entries above the pivot, beta on it, v below) and shifts the register file left by one column,
+// so the loop body is the same for every j and need not be unrolled 32 times.
+// level 1: the chunk's rows are dense; level > 1: every sub-block of 32 rows is an upper triangle (the R of a lower-level chunk) --
+// entries below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
+// Sum over the 64 lanes, the same value returned to every lane: four butterfly steps inside a row of 16 lanes by DPP (quad
+// permutes, half-row and row mirrors), the two row broadcasts that carry the row sums to lane 63, one v_readlane -- seven vector
+// instructions, no LDS crossbar (a __shfl_xor tree is six ds_bpermute round trips, one after the other).
+template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T ba_dpp_add(T v)
+{
+    return v + __builtin_amdgcn_update_dpp((T)0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <typename T> __device__ __forceinline__ T ba_wave_sum_all(T v)
+{
+    v = ba_dpp_add<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v = ba_dpp_add<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+    v = ba_dpp_add<0x141, 0xf>(v); // row_half_mirror
+    v = ba_dpp_add<0x140, 0xf>(v); // row_mirror: every lane holds the sum of its row of 16
+    v = ba_dpp_add<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = ba_dpp_add<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return ba_readlane63(v);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                  T *__restrict__ tau /* [chunks][32] */)
+                                                  T *__restrict__ tau /* [chunks][32] */, int nch)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH;
-    __shared__ T Ac[BA_QR_PB][CH + 1];
-    __shared__ T red[8][BA_QR_PB + 1];
-    __shared__ T sc_s[4];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64;
+    const int lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nch) return;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
-#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
-    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
-        const int c = idx / CH, l = idx - c * CH;
-        T v = 0;
-        if (c < bw && l < rows && (level == 1 || (l & 31) <= c)) v = A[(size_t)(c0 + c) * lda + ba_qr_row<T>(row0, g, l, stride)];
-        Ac[c][l] = v;
+    T a[RPL][BA_QR_PB];
+    size_t grow[RPL];
+#pragma unroll
+    for (int e = 0; e < RPL; e++) {
+        const int l = lane + 64 * e;
+        grow[e] = ba_qr_row<T>(row0, g, l, stride);
+#pragma unroll
+        for (int c = 0; c < BA_QR_PB; c++)
+            a[e][c] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? A[(size_t)(c0 + c) * lda + grow[e]] : (T)0;
     }
-    __syncthreads();
-    const int cc = tid & 31, rg = tid >> 5; // column / row group of this thread in the update phase
     for (int j = 0; j < bw; j++) {
-        // |x|^2 below the pivot
-        T xn = 0;
-        for (int l = j + 1 + tid; l < rows; l += 256) xn += Ac[j][l] * Ac[j][l];
+        T part = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) xn += __shfl_down(xn, off, 64);
-        if ((tid & 63) == 0) red[tid >> 6][0] = xn;
-        __syncthreads();
-        if (tid == 0) {
-            const T x2 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-            const T alpha = Ac[j][j];
-            T tj = 0, sc = 0, beta = alpha;
-            if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-                beta = sqrt(alpha * alpha + x2);
-                if (alpha > (T)0) beta = -beta;
-                tj = (beta - alpha) / beta;
-                sc = (T)1.0 / (alpha - beta);
-            }
-            sc_s[0] = tj; sc_s[1] = sc; sc_s[2] = beta;
-            tau[(size_t)g * BA_QR_PB + j] = tj;
+        for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][0] * a[e][0] : (T)0;
+        const T x2 = ba_wave_sum_all<T>(part);
+        const T alpha = __shfl(a[0][0], j, 64); // row j lives in lane j, e = 0 (j < 32)
+        T tj = 0, sc = 0, beta = alpha;
+        if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
+            beta = sqrt(alpha * alpha + x2);
+            if (alpha > (T)0) beta = -beta;
+            tj = (beta - alpha) / beta;
+            sc = (T)1.0 / (alpha - beta);
         }
-        __syncthreads();
-        const T tj = sc_s[0], sc = sc_s[1];
-        for (int l = j + 1 + tid; l < rows; l += 256) Ac[j][l] *= sc;
-        if (tid == 0) Ac[j][j] = sc_s[2];
-        __syncthreads();
-        // w_c = tau (a_c[j] + v . a_c) for the columns behind j, then a_c -= v w_c.  Fixed trip counts, unrolled: the LDS reads of
-        // sixteen rows are in flight together (a rolled loop paid the LDS latency per row: 11 us per column).  Rows <= j hold R
-        // entries of column j, not reflector entries: masked.
-        T dot = 0;
-        if (cc > j && cc < bw) {
-#pragma unroll 16
-            for (int it = 0; it < CH / 8; it++) {
-                const int l = rg + 8 * it;
-                const T v = l > j ? Ac[j][l] : (T)0; // (rows beyond the chunk's last sub-block are zero-filled)
-                dot += v * Ac[cc][l];
-            }
-        }
-        red[rg][cc] = dot;
-        __syncthreads();
-        if (cc > j && cc < bw) {
-            T d = 0;
+        if (lane == 0) tau[(size_t)g * BA_QR_PB + j] = tj;
+        T v[RPL];
 #pragma unroll
-            for (int q = 0; q < 8; q++) d += red[q][cc];
-            const T w = tj * (Ac[cc][j] + d);
-#pragma unroll 16
-            for (int it = 0; it < CH / 8; it++) {
-                const int l = rg + 8 * it;
-                const T v = l > j ? Ac[j][l] : (T)0;
-                Ac[cc][l] -= v * w;
-            }
-            if (rg == 0) Ac[cc][j] -= w;
+        for (int e = 0; e < RPL; e++) {
+            const int l = lane + 64 * e;
+            v[e] = l > j ? a[e][0] * sc : (l == j ? (T)1 : (T)0);
+            a[e][0] = l > j ? v[e] : (l == j ? beta : a[e][0]);
         }
-        __syncthreads();
-    }
-#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
-    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
-        const int c = idx / CH, l = idx - c * CH;
-        if (c < bw && l < rows && (level == 1 || (l & 31) <= c)) A[(size_t)(c0 + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = Ac[c][l];
+        // w_c = tau (v . a_c) for the columns behind, a_c -= v w_c  (v is 1 on row j, zero above: rows <= j of a_c are R entries)
+#pragma unroll
+        for (int c = 1; c < BA_QR_PB; c++) {
+            T pd = 0;
+#pragma unroll
+            for (int e = 0; e < RPL; e++) pd += v[e] * a[e][c];
+            const T w = tj * ba_wave_sum_all<T>(pd);
+#pragma unroll
+            for (int e = 0; e < RPL; e++) a[e][c] -= v[e] * w;
+        }
+        // retire column j and shift the rest one position to the left
+#pragma unroll
+        for (int e = 0; e < RPL; e++) {
+            const int l = lane + 64 * e;
+            if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = a[e][0];
+#pragma unroll
+            for (int c = 0; c + 1 < BA_QR_PB; c++) a[e][c] = a[e][c + 1];
+            a[e][BA_QR_PB - 1] = 0;
+        }
     }
 }
 
-// ---- the reflectors of one chunk applied to 32 trailing columns ----------------------------------------------------------
-// grid (chunks, column tiles); the tile (chunk rows x 32 columns) lives in LDS while the 32 reflectors pass over it.
+// ---- the reflectors of one chunk applied to 32 trailing columns: one wavefront per (chunk, column tile), in registers --------
 // Reflector j of the chunk: 1 at local row j, zero above; below: level 1 -- the stored panel column; level > 1 -- in every
-// sub-block behind the first only the rows t <= j (the triangle it annihilated).
+// sub-block behind the first only the rows t <= j (the triangle it annihilated).  The next reflector's entries are requested
+// while the current one is applied.
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                  const T *__restrict__ tau, int col0, int col1)
+                                                  const T *__restrict__ tau, int col0, int col1, int nch, int nct)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH;
-    __shared__ T B[BA_QR_PB][CH + 1];
-    __shared__ T vs[CH];
-    __shared__ T red[8][BA_QR_PB + 1];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int cb = col0 + BA_QR_PB * blockIdx.y, ncol = min(BA_QR_PB, col1 - cb);
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64;
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nch * nct) return;
+    const int g = wid % nch, ct = wid / nch; // (neighbouring wavefronts share a column tile and walk neighbouring chunks)
+    const int cb = col0 + BA_QR_PB * ct, ncol = min(BA_QR_PB, col1 - cb);
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
-#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
-    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
-        const int c = idx / CH, l = idx - c * CH;
-        B[c][l] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] : (T)0;
-    }
-    const int cc = tid & 31, rg = tid >> 5;
-    // reflector j as this thread's CH / 256 rows of it (l = tid + 256 e): 1 at row j, zero above, the stored entries below
-    auto vload = [&](int j, T (&v)[CH / 256]) {
+    T b[RPL][BA_QR_PB];
+    size_t grow[RPL];
 #pragma unroll
-        for (int e = 0; e < CH / 256; e++) {
-            const int l = tid + 256 * e;
+    for (int e = 0; e < RPL; e++) {
+        const int l = lane + 64 * e;
+        grow[e] = ba_qr_row<T>(row0, g, l, stride);
+#pragma unroll
+        for (int c = 0; c < BA_QR_PB; c++) b[e][c] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + grow[e]] : (T)0;
+    }
+    auto vload = [&](int j, T (&v)[RPL]) {
+#pragma unroll
+        for (int e = 0; e < RPL; e++) {
+            const int l = lane + 64 * e;
             T x = 0;
             if (l == j) x = 1;
-            else if (l > j && l < rows && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j)))
-                x = A[(size_t)(c0 + j) * lda + ba_qr_row<T>(row0, g, l, stride)];
+            else if (l > j && l < rows && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j))) x = A[(size_t)(c0 + j) * lda + grow[e]];
             v[e] = x;
         }
     };
-    T vn[CH / 256];
+    T vn[RPL];
     vload(0, vn);
     for (int j = 0; j < bw; j++) {
         const T tj = tau[(size_t)g * BA_QR_PB + j];
-        __syncthreads(); // (the previous reflector's reads of vs, and the fill of B on the first pass)
+        T v[RPL];
 #pragma unroll
-        for (int e = 0; e < CH / 256; e++) vs[tid + 256 * e] = vn[e];
-        if (j + 1 < bw) vload(j + 1, vn); // the next reflector comes in from L2 under this one's arithmetic
-        __syncthreads();
-        T dot = 0;
-#pragma unroll 16
-        for (int it = 0; it < CH / 8; it++) {
-            const int l = rg + 8 * it;
-            dot += vs[l] * B[cc][l]; // (vs is zero above row j and beyond the chunk's rows)
-        }
-        red[rg][cc] = dot;
-        __syncthreads();
-        T d = 0;
+        for (int e = 0; e < RPL; e++) v[e] = vn[e];
+        if (j + 1 < bw) vload(j + 1, vn);
 #pragma unroll
-        for (int q = 0; q < 8; q++) d += red[q][cc];
-        const T w = tj * d;
-#pragma unroll 16
-        for (int it = 0; it < CH / 8; it++) {
-            const int l = rg + 8 * it;
-            B[cc][l] -= vs[l] * w;
+        for (int c = 0; c < BA_QR_PB; c++) {
+            T pd = 0;
+#pragma unroll
+            for (int e = 0; e < RPL; e++) pd += v[e] * b[e][c];
+            const T w = tj * ba_wave_sum_all<T>(pd);
+#pragma unroll
+            for (int e = 0; e < RPL; e++) b[e][c] -= v[e] * w;
         }
     }
-    __syncthreads();
-#pragma unroll 8 // (eight global accesses in flight per thread: a rolled loop paid the L2 round trip 128 times)
-    for (int idx = tid; idx < BA_QR_PB * CH; idx += 256) {
-        const int c = idx / CH, l = idx - c * CH;
-        if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + ba_qr_row<T>(row0, g, l, stride)] = B[c][l];
+#pragma unroll
+    for (int e = 0; e < RPL; e++) {
+        const int l = lane + 64 * e;
+#pragma unroll
+        for (int c = 0; c < BA_QR_PB; c++)
+            if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + grow[e]] = b[e][c];
     }
 }
 
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, s
 }
 
 // Host side: QR of the (mrows x D) matrix A (+ rhs in column D) on `st`, then y = argmin || A y - rhs ||.
-// A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: room for (ceil(mrows / CH) + 2) * 32 scalars per level, 4 levels.
+// A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: room for (ceil(mrows / CH) + 2) * 32 scalars per level, 8 levels
+// (CH = 256 / 128 rows: 181 633 rows are 5 levels in fp32, 7 in fp64).
 template <typename T>
 inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y)
 {
@@ -282,10 +287,11 @@ inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *t
         for (int level = 1;; level++) {
             const int nch = (nsb + NSB - 1) / NSB;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
-            hipLaunchKernelGGL((k_qr_chunk<T>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl);
+            hipLaunchKernelGGL((k_qr_chunk<T>), dim3((nch + 3) / 4), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
             const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB;
             if (nct > 0)
-                hipLaunchKernelGGL((k_qr_apply<T>), dim3(nch, nct), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1);
+                hipLaunchKernelGGL((k_qr_apply<T>), dim3((unsigned)(((long long)nch * nct + 3) / 4)), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb,
+                                   (const T *)tl, col0, col1, nch, nct);
             if (nch == 1) break;
             nsb = nch;
             stride *= NSB;
