@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #define BA_QR_PB 32 /* panel width = rows of a sub-block */
+#define BA_QR_CW 8  /* trailing columns per wavefront of k_qr_apply */
 
 __device__ __forceinline__ float ba_readlane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
 __device__ __forceinline__ double ba_readlane63(double v)
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
     }
 }
 
-// ---- one chunk of a TSQR level: Householder QR of its rows of the panel, one WAVEFRONT per chunk, in registers ---------------
-// Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them) and all 32 panel columns: no LDS tile, no barrier.
-// Step j works on the column at register position 0 (norm below the pivot by a wave reduction, the scalars redundantly in every
-// lane, the reflector v in RPL registers), updates the positions behind it -- one wave reduction per column for v . a_c --,
-// retires position 0 to memory (R entries above the pivot, beta on it, v below) and shifts the register file left by one column,
-// so the loop body is the same for every j and need not be unrolled 32 times.
+// ---- one chunk of a TSQR level: Householder QR of its rows of the panel, in registers --------------------------------------
+// Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them); the 32 panel columns are dealt to the four wavefronts of
+// the workgroup cyclically.  Step j: the owner of column j forms the reflector (norm below the pivot by a wave reduction, the
+// scalars redundantly in every lane), hands it to the others through LDS and retires the column to memory (R entries above the
+// pivot, beta on it, v below), shifting its registers left by one column so that its next column is at position 0 again -- the
+// loop body is the same for every j; then every wavefront updates its own columns, one wave reduction per column for v . a_c.
 // level 1: the chunk's rows are dense; level > 1: every sub-block of 32 rows is an upper triangle (the R of a lower-level chunk) --
 // entries below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
 // Sum over the 64 lanes, the same value returned to every lane: four butterfly steps inside a row of 16 lanes by DPP (quad
@@ -134,85 +135,95 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
                                                   T *__restrict__ tau /* [chunks][32] */, int nch)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64;
-    const int lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= nch) return;
+    // One workgroup per chunk, wave w owns the panel columns c with (c & 3) == w (eight of them, CW): the column that step j
+    // retires is always at register position 0 of its owner.  The owner forms the reflector (norm, scalars), leaves it in LDS
+    // (double-buffered: one barrier per step) and retires its column; every wave then updates its own columns.
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64, CW = BA_QR_PB / 4;
+    __shared__ T vs[2][CH];
+    __shared__ T tj_s[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = blockIdx.x;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
-    T a[RPL][BA_QR_PB];
+    T a[RPL][CW];
     size_t grow[RPL];
 #pragma unroll
     for (int e = 0; e < RPL; e++) {
         const int l = lane + 64 * e;
         grow[e] = ba_qr_row<T>(row0, g, l, stride);
 #pragma unroll
-        for (int c = 0; c < BA_QR_PB; c++)
-            a[e][c] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? A[(size_t)(c0 + c) * lda + grow[e]] : (T)0;
+        for (int q = 0; q < CW; q++) {
+            const int c = 4 * q + wv;
+            a[e][q] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? A[(size_t)(c0 + c) * lda + grow[e]] : (T)0;
+        }
     }
     for (int j = 0; j < bw; j++) {
-        T part = 0;
+        if ((j & 3) == wv) { // (wave-uniform)
+            T part = 0;
 #pragma unroll
-        for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][0] * a[e][0] : (T)0;
-        const T x2 = ba_wave_sum_all<T>(part);
-        const T alpha = __shfl(a[0][0], j, 64); // row j lives in lane j, e = 0 (j < 32)
-        T tj = 0, sc = 0, beta = alpha;
-        if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-            beta = sqrt(alpha * alpha + x2);
-            if (alpha > (T)0) beta = -beta;
-            tj = (beta - alpha) / beta;
-            sc = (T)1.0 / (alpha - beta);
+            for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][0] * a[e][0] : (T)0;
+            const T x2 = ba_wave_sum_all<T>(part);
+            const T alpha = __shfl(a[0][0], j, 64); // row j lives in lane j, e = 0 (j < 32)
+            T tj = 0, sc = 0, beta = alpha;
+            if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
+                beta = sqrt(alpha * alpha + x2);
+                if (alpha > (T)0) beta = -beta;
+                tj = (beta - alpha) / beta;
+                sc = (T)1.0 / (alpha - beta);
+            }
+            if (lane == 0) { tau[(size_t)g * BA_QR_PB + j] = tj; tj_s[j & 1] = tj; }
+#pragma unroll
+            for (int e = 0; e < RPL; e++) {
+                const int l = lane + 64 * e;
+                const T ve = l > j ? a[e][0] * sc : (l == j ? (T)1 : (T)0);
+                vs[j & 1][l] = ve;
+                const T keep = l > j ? ve : (l == j ? beta : a[e][0]);
+                if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = keep; // retire column j
+#pragma unroll
+                for (int q = 0; q + 1 < CW; q++) a[e][q] = a[e][q + 1];
+                a[e][CW - 1] = 0;
+            }
         }
-        if (lane == 0) tau[(size_t)g * BA_QR_PB + j] = tj;
+        __syncthreads();
+        const T tj = tj_s[j & 1];
         T v[RPL];
 #pragma unroll
-        for (int e = 0; e < RPL; e++) {
-            const int l = lane + 64 * e;
-            v[e] = l > j ? a[e][0] * sc : (l == j ? (T)1 : (T)0);
-            a[e][0] = l > j ? v[e] : (l == j ? beta : a[e][0]);
-        }
-        // w_c = tau (v . a_c) for the columns behind, a_c -= v w_c  (v is 1 on row j, zero above: rows <= j of a_c are R entries)
+        for (int e = 0; e < RPL; e++) v[e] = vs[j & 1][lane + 64 * e];
+        // w_c = tau (v . a_c) for this wave's columns behind j, a_c -= v w_c  (v is 1 on row j, zero above)
 #pragma unroll
-        for (int c = 1; c < BA_QR_PB; c++) {
+        for (int q = 0; q < CW; q++) {
             T pd = 0;
 #pragma unroll
-            for (int e = 0; e < RPL; e++) pd += v[e] * a[e][c];
+            for (int e = 0; e < RPL; e++) pd += v[e] * a[e][q];
             const T w = tj * ba_wave_sum_all<T>(pd);
 #pragma unroll
-            for (int e = 0; e < RPL; e++) a[e][c] -= v[e] * w;
-        }
-        // retire column j and shift the rest one position to the left
-#pragma unroll
-        for (int e = 0; e < RPL; e++) {
-            const int l = lane + 64 * e;
-            if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = a[e][0];
-#pragma unroll
-            for (int c = 0; c + 1 < BA_QR_PB; c++) a[e][c] = a[e][c + 1];
-            a[e][BA_QR_PB - 1] = 0;
+            for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * w;
         }
     }
 }
 
-// ---- the reflectors of one chunk applied to 32 trailing columns: one wavefront per (chunk, column tile), in registers --------
+// ---- the reflectors of one chunk applied to CW trailing columns: one wavefront per (chunk, column strip), in registers ----------
 // Reflector j of the chunk: 1 at local row j, zero above; below: level 1 -- the stored panel column; level > 1 -- in every
 // sub-block behind the first only the rows t <= j (the triangle it annihilated).  The next reflector's entries are requested
-// while the current one is applied.
+// while the current one is applied.  Eight columns per wavefront: 32 registers of tile, eight wavefronts per SIMD hide the L2
+// latency of the reflector loads, and a task is 32 x 8 short dependent chains (6 us) -- the upper levels of the tree, where a
+// launch holds a handful of tasks, take as long as one task.
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
                                                   const T *__restrict__ tau, int col0, int col1, int nch, int nct)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64;
+    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64, CW = BA_QR_CW;
     const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= nch * nct) return;
-    const int g = wid % nch, ct = wid / nch; // (neighbouring wavefronts share a column tile and walk neighbouring chunks)
-    const int cb = col0 + BA_QR_PB * ct, ncol = min(BA_QR_PB, col1 - cb);
+    const int g = wid % nch, ct = wid / nch; // (neighbouring wavefronts share a column strip and walk neighbouring chunks)
+    const int cb = col0 + CW * ct, ncol = min(CW, col1 - cb);
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
-    T b[RPL][BA_QR_PB];
+    T b[RPL][CW];
     size_t grow[RPL];
 #pragma unroll
     for (int e = 0; e < RPL; e++) {
         const int l = lane + 64 * e;
         grow[e] = ba_qr_row<T>(row0, g, l, stride);
 #pragma unroll
-        for (int c = 0; c < BA_QR_PB; c++) b[e][c] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + grow[e]] : (T)0;
+        for (int c = 0; c < CW; c++) b[e][c] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + grow[e]] : (T)0;
     }
     auto vload = [&](int j, T (&v)[RPL]) {
 #pragma unroll
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda,
         for (int e = 0; e < RPL; e++) v[e] = vn[e];
         if (j + 1 < bw) vload(j + 1, vn);
 #pragma unroll
-        for (int c = 0; c < BA_QR_PB; c++) {
+        for (int c = 0; c < CW; c++) {
             T pd = 0;
 #pragma unroll
             for (int e = 0; e < RPL; e++) pd += v[e] * b[e][c];
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda,
     for (int e = 0; e < RPL; e++) {
         const int l = lane + 64 * e;
 #pragma unroll
-        for (int c = 0; c < BA_QR_PB; c++)
+        for (int c = 0; c < CW; c++)
             if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + grow[e]] = b[e][c];
     }
 }
@@ -287,8 +298,8 @@ inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *t
         for (int level = 1;; level++) {
             const int nch = (nsb + NSB - 1) / NSB;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
-            hipLaunchKernelGGL((k_qr_chunk<T>), dim3((nch + 3) / 4), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
-            const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB;
+            hipLaunchKernelGGL((k_qr_chunk<T>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            const int nct = (col1 - col0 + BA_QR_CW - 1) / BA_QR_CW;
             if (nct > 0)
                 hipLaunchKernelGGL((k_qr_apply<T>), dim3((unsigned)(((long long)nch * nct + 3) / 4)), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb,
                                    (const T *)tl, col0, col1, nch, nct);
