@@ -1,5 +1,6 @@
 // Dev tool: times the dense LDL^T kernels of ba_dense.hip.h on a random SPD matrix (not part of the product).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -DBA_STAMP -I bundleadjustment_benchmarks_amd/csrc scripts/bench_dense.hip -o /tmp/bench_dense
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form [-DBA_STAMP] -I bundleadjustment_benchmarks_amd/csrc scripts/bench_dense.hip -o scripts/bench_dense.bin
+// (the library's flags, csrc/Makefile; scripts/dense_trace.sh <tag> bench_dense.bin <D> lists the per-launch times of a factorisation)
 #ifndef BENCH_NB
 #define BENCH_NB 64
 #endif
