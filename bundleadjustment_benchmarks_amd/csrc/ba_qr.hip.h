@@ -286,26 +286,44 @@ __global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, s
 // Host side: QR of the (mrows x D) matrix A (+ rhs in column D) on `st`, then y = argmin || A y - rhs ||.
 // A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: room for (ceil(mrows / CH) + 2) * 32 scalars per level, 8 levels
 // (CH = 256 / 128 rows: 181 633 rows are 5 levels in fp32, 7 in fp64).
+// st2 != nullptr (with two events): the trailing updates run on st2 beside the panel's chunk chain -- level L + 1 of the chain only
+// needs the panel's own R's from level L, not the trailing update of level L -- and the next panel waits for the last of them
+// (fork / join by events: also valid inside a stream capture).  6.2 -> 5.3 ms per trial at config 3.  With look-ahead on top (every
+// level's reflectors to the next panel's 32 columns first, on `st`, so that the next chain starts before the rest is done) it was
+// 5.7 ms: five more launches of one task's latency each on the critical stream cost more than the overlap gives.
 template <typename T>
-inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y)
+inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, hipStream_t st2 = nullptr,
+                        hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
 {
     constexpr int NSB = ba_qr_cfg<T>::NSB;
+    const bool two = st2 != nullptr && ev_chunk != nullptr && ev_apply != nullptr;
     for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
         const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
         const int col0 = c0 + bw, col1 = D + 1; // trailing columns incl. the right-hand side
         int nsb = (mrows - c0 + BA_QR_PB - 1) / BA_QR_PB; // 32-row blocks from the panel's first row down
         long long stride = BA_QR_PB;
+        const int nct = (col1 - col0 + BA_QR_CW - 1) / BA_QR_CW;
         for (int level = 1;; level++) {
             const int nch = (nsb + NSB - 1) / NSB;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
             hipLaunchKernelGGL((k_qr_chunk<T>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
-            const int nct = (col1 - col0 + BA_QR_CW - 1) / BA_QR_CW;
-            if (nct > 0)
-                hipLaunchKernelGGL((k_qr_apply<T>), dim3((unsigned)(((long long)nch * nct + 3) / 4)), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb,
+            if (nct > 0) {
+                hipStream_t sa = st;
+                if (two) {
+                    (void)hipEventRecord(ev_chunk, st);
+                    (void)hipStreamWaitEvent(st2, ev_chunk, 0);
+                    sa = st2;
+                }
+                hipLaunchKernelGGL((k_qr_apply<T>), dim3((unsigned)(((long long)nch * nct + 3) / 4)), dim3(256), 0, sa, A, lda, c0, bw, c0, level, stride, nsb,
                                    (const T *)tl, col0, col1, nch, nct);
+            }
             if (nch == 1) break;
             nsb = nch;
             stride *= NSB;
+        }
+        if (two && nct > 0) { // the next panel (and the back substitution) read what the trailing updates wrote
+            (void)hipEventRecord(ev_apply, st2);
+            (void)hipStreamWaitEvent(st, ev_apply, 0);
         }
     }
     hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)D, st, (const T *)A, lda, D, y);

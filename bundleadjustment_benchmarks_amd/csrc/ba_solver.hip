@@ -130,6 +130,8 @@ template <typename T> struct Solver final : SolverBase {
     // QRKIT (single shard): dense J2bot (+ rhs column) for the Householder QR of the right block, its reflector scalars, the thin Q rows
     DevBuf<T> d_qA, d_qtau, d_q1obs, d_q1lam;
     size_t q_lda = 0, q_tau_stride = 0;
+    hipStream_t st_qr = nullptr;   // second stream of the dense QR: trailing updates beside the panel's chunk chain (ba_qr_solve)
+    hipEvent_t ev_qr[2] = {nullptr, nullptr};
     int q_rows = 0;
     bool dense_qr() const { return (kind == BA_QRKIT || kind == BA_QRSPQR) && !sharded(); } // (QRSPQR: see include/ba_mi355x.h)
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
@@ -161,6 +163,8 @@ template <typename T> struct Solver final : SolverBase {
         if (h_log) (void)hipHostFree((void *)h_log);
         if (comm) ba_rccl_destroy(comm);
         if (own_stream && st) (void)hipStreamDestroy(st);
+        if (st_qr) (void)hipStreamDestroy(st_qr);
+        for (hipEvent_t e : ev_qr) if (e) (void)hipEventDestroy(e);
     }
 
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
@@ -310,6 +314,10 @@ template <typename T> struct Solver final : SolverBase {
                     for (int i2 = sx.pt_ptr[j]; i2 < i; i2++)
                         if (sx.obs_cam[i] == sx.obs_cam[i2]) return BA_ERR_ARG;
             q_rows = 2 * Kl + 3 * Ml + D;
+            if (!getenv("BA_QR_ONE_STREAM")) {
+                HIPCHK(hipStreamCreateWithFlags(&st_qr, hipStreamNonBlocking));
+                for (auto &e : ev_qr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
             q_lda = (size_t)q_rows + 64;
             q_tau_stride = (size_t)((q_rows + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB;
             AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, 8 * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
@@ -513,7 +521,7 @@ template <typename T> struct Solver final : SolverBase {
     }
     void launch_qrkit_solve()
     {
-        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p);
+        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p, st_qr, ev_qr[0], ev_qr[1]);
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
 
