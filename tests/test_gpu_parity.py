@@ -404,13 +404,15 @@ def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
 
 
-@pytest.mark.parametrize("ncams,with_oracle_step", [(180, True), (340, False)])
+@pytest.mark.parametrize("ncams,with_oracle_step", [(180, True), (340, False), (600, False)])
 def test_fused_factor_paths(ba, O, gpu_ok, ncams, with_oracle_step):
-    """The dense LDL^T switches kernels with the size of the reduced system: below 24 block columns a launch per panel and
-    per update; from D = 9 N >= 1473 the fused look-ahead step with row workgroups and hand-off flags (one workgroup per CU;
-    N = 180: 26 block columns), from 48 block columns the two-workgroups-per-CU variant (N = 340: 48 block columns).  The
-    backward sweep is the one-launch data-flow kernel in every case.  N = 180 is compared with the oracle's step; for
-    N = 340 (a 9 GFLOP factorisation on one CPU core) the backward error of the step in the normal equations is checked."""
+    """The dense LDL^T switches kernels with the size of the reduced system: the fused look-ahead step with row workgroups and
+    hand-off flags, one workgroup per CU (k_ldlt_step; N = 180: 26 block columns); from 48 block columns the two-workgroups-per-CU
+    variant (k_ldlt_step2; N = 340: 48 block columns, single-panel steps with 64 x 64 tiles throughout); beyond 72 block columns
+    the trailing update by pairs of panels on 128 x 128 macro tiles for the leading steps (N = 600: 85 block columns, 13 of
+    them in the pair phase, the odd / even step roles and the hand-over to the single-panel tail included).  The backward sweep
+    is the one-launch data-flow kernel in every case.  N = 180 is compared with the oracle's step; for the larger ones (9 and
+    50 GFLOP factorisations on one CPU core) the backward error of the step in the normal equations is checked."""
     npts = 12 * ncams
     p = ba.Problem.synthetic(ncams, npts, 5 * npts, 4000 + ncams)
     po = to_oracle(p)
