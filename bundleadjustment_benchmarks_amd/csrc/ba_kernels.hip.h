@@ -407,14 +407,27 @@ __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__r
         Bt[3 * rr + 1] = b1 - l10 * Bt[3 * rr];
         Bt[3 * rr + 2] = b2 - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
     }
-    T *o = rec + (size_t)i * BA_REC;
+    // The record (30 of its 32 scalars) leaves in one burst of 16-byte stores at the end: a record is two cache lines that only this
+    // thread writes, and stores trickling out between the Jacobian loads left them half-written in L2 for a microsecond -- evicted
+    // partial lines made 96 MB of HBM writes out of 58 MB at config 4 (rocprofv3 WRITE_SIZE).
+    T z[BA_REC];
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
-        const T z0 = a0 * Bt[0] + a1 * Bt[3], z1 = a0 * Bt[1] + a1 * Bt[4], z2 = a0 * Bt[2] + a1 * Bt[5];
-        o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
+        z[3 * c] = a0 * Bt[0] + a1 * Bt[3]; z[3 * c + 1] = a0 * Bt[1] + a1 * Bt[4]; z[3 * c + 2] = a0 * Bt[2] + a1 * Bt[5];
     }
-    o[BA_REC_DINV] = i0; o[BA_REC_DINV + 1] = i1; o[BA_REC_DINV + 2] = i2;
+    z[BA_REC_DINV] = i0; z[BA_REC_DINV + 1] = i1; z[BA_REC_DINV + 2] = i2;
+    z[BA_REC_DINV + 3] = 0; z[BA_REC_DINV + 4] = 0;
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    vec_t *o = (vec_t *)(rec + (size_t)i * BA_REC);
+    constexpr int VW = 16 / sizeof(T);
+#pragma unroll
+    for (int q = 0; q < BA_REC / VW; q++) {
+        vec_t v;
+#pragma unroll
+        for (int u = 0; u < VW; u++) v[u] = z[VW * q + u];
+        o[q] = v;
+    }
 }
 
 // ---- K4 (QRCHOL / QRKIT left block): Householder QR of [sqrt(lambda) I3 ; (Jp)_j] per point ------------------
