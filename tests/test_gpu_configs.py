@@ -134,8 +134,8 @@ def test_cfg5_full_size(ba, O, gpu_ok):
       * the reduced camera matrix S and its rhs against the oracle's elimination + assembly (no factorisation) on a point
         subset of the same problem (first 20 000 points, all 1024 cameras -> the same 9216 x 9216 system layout);
       * the full step by its backward error in the normal equations and by the energy decrease it produces.
-    The two-workgroups-per-CU dense-factor variant (>= 48 block columns) and the launch-per-pair back sweep fallback are the
-    ones that run here."""
+    The two-workgroups-per-CU dense-factor variant with its pair phase (144 block columns: macro-tile updates by pairs of panels
+    for the first 72 steps, single-panel steps behind) and the data-flow back sweep with 72 groups are the ones that run here."""
     p = ba.Problem.synthetic(1024, 500000, 4000000, 1005)
     po = to_oracle(p)
     cam = O.init_cams(po)
