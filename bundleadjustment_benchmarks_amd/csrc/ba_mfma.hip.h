@@ -19,4 +19,33 @@ __device__ __forceinline__ ba_d4 ba_mfma(double a, double b, ba_d4 c) { return _
 __device__ __forceinline__ ba_f4 ba_mfma(float a, float b, ba_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 template <typename T> __device__ __forceinline__ int ba_crow(int lk, int v) { return sizeof(T) == 8 ? lk + 4 * v : 4 * lk + v; }
 
+
+// ---- wave reduction by DPP (dense back sweep, QRKIT QR) -------------------------------------------------------------
+__device__ __forceinline__ float ba_readlane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ double ba_readlane63(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
+
+// Sum over the 64 lanes, the same value returned to every lane: four butterfly steps inside a row of 16 lanes by DPP (quad
+// permutes, half-row and row mirrors), the two row broadcasts that carry the row sums to lane 63, one v_readlane -- seven vector
+// instructions, no LDS crossbar (a __shfl_xor tree is six ds_bpermute round trips, one after the other).
+template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T ba_dpp_add(T v)
+{
+    return v + __builtin_amdgcn_update_dpp((T)0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <typename T> __device__ __forceinline__ T ba_wave_sum_all(T v)
+{
+    v = ba_dpp_add<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v = ba_dpp_add<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+    v = ba_dpp_add<0x141, 0xf>(v); // row_half_mirror
+    v = ba_dpp_add<0x140, 0xf>(v); // row_mirror: every lane holds the sum of its row of 16
+    v = ba_dpp_add<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = ba_dpp_add<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return ba_readlane63(v);
+}
+
 #endif

@@ -24,17 +24,10 @@
 #define BA_QR_HIP_H
 
 #include <hip/hip_runtime.h>
+#include "ba_mfma.hip.h"
 
 #define BA_QR_PB 32 /* panel width = rows of a sub-block */
 #define BA_QR_CW 8  /* trailing columns per wavefront of k_qr_apply */
-
-__device__ __forceinline__ float ba_readlane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
-__device__ __forceinline__ double ba_readlane63(double v)
-{
-    const long long b = __builtin_bit_cast(long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
-}
 
 template <typename T> struct ba_qr_cfg {
     static constexpr int NSB = sizeof(T) == 4 ? 8 : 4; // sub-blocks (of 32 rows) per chunk
@@ -113,24 +106,6 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
 // loop body is the same for every j; then every wavefront updates its own columns, one wave reduction per column for v . a_c.
 // level 1: the chunk's rows are dense; level > 1: every sub-block of 32 rows is an upper triangle (the R of a lower-level chunk) --
 // entries below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
-// Sum over the 64 lanes, the same value returned to every lane: four butterfly steps inside a row of 16 lanes by DPP (quad
-// permutes, half-row and row mirrors), the two row broadcasts that carry the row sums to lane 63, one v_readlane -- seven vector
-// instructions, no LDS crossbar (a __shfl_xor tree is six ds_bpermute round trips, one after the other).
-template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T ba_dpp_add(T v)
-{
-    return v + __builtin_amdgcn_update_dpp((T)0, v, CTRL, ROW_MASK, 0xf, false);
-}
-template <typename T> __device__ __forceinline__ T ba_wave_sum_all(T v)
-{
-    v = ba_dpp_add<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
-    v = ba_dpp_add<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
-    v = ba_dpp_add<0x141, 0xf>(v); // row_half_mirror
-    v = ba_dpp_add<0x140, 0xf>(v); // row_mirror: every lane holds the sum of its row of 16
-    v = ba_dpp_add<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-    v = ba_dpp_add<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-    return ba_readlane63(v);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
                                                   T *__restrict__ tau /* [chunks][32] */, int nch)
