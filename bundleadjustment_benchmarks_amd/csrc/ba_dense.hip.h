@@ -1074,12 +1074,17 @@ __global__ void k_fill_sentinel(int n, T *__restrict__ x)
 
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zrow, int nblk, T *__restrict__ S, const T *__restrict__ Winv,
-                                                       T *__restrict__ x, T *__restrict__ errw = nullptr, int spin_limit = BA_SWEEP_SPINS,
-                                                       int skip_group = -1 /* self-test only: this group never publishes */)
+                                                       T *__restrict__ x, T *__restrict__ zh /* [columns], armed like x */, T *__restrict__ errw = nullptr,
+                                                       int spin_limit = BA_SWEEP_SPINS, int skip_group = -1 /* self-test only: this group never publishes */)
 {
     static_assert(NB == 64, "written for 64-wide block columns");
     __shared__ T zs[2 * NB], xin[2 * NB], xs[2 * NB], part[4][NB], part2[2][2 * NB];
-    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    // TWO workgroups per group.  A workgroup pulls the 128 KB block of L of every later group through one CU (~50 GB/s: 2.6 us per
+    // block), and a hop of the chain could not be shorter than that.  The later groups are dealt to the two by the parity of their
+    // distance: the main workgroup (role 0) takes g + 1, g + 3, ... -- the last one to arrive among them -- and solves the group;
+    // the helper (role 1) takes g + 2, g + 4, ..., so it is done one hop BEFORE the chain reaches the group and hands its partial
+    // sums over (zh, same sentinel protocol as x) off the critical path.  Each now needs a block every second hop.
+    const int tid = threadIdx.x, g = blockIdx.x >> 1, role = blockIdx.x & 1, G = gridDim.x >> 1;
     if (g == skip_group) return;
     const bool odd = (nblk & 1) != 0;
     const int fb = odd ? max(0, 2 * g - 1) : 2 * g, nbg = (odd && g == 0) ? 1 : 2; // first block column / block columns of this group
@@ -1091,16 +1096,18 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
     // with a wait behind every single load -- sixteen L2 round trips in a row at the head of the sweep)
     const T *W1p = nbg == 2 ? W1 : W0;
     T w1[16], w0[16], l10[16];
+    if (role == 0) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int k = 16 * q + t;
-        w0[t] = W0[k * NB + j];
-        w1[t] = W1p[k * NB + j];
-        l10[t] = S[(size_t)(c0 + j) * ld + c0 + NB + k]; // L(c0 + 64 + k, c0 + j); unused (finite padding) when nbg == 1
+        for (int t = 0; t < 16; t++) {
+            const int k = 16 * q + t;
+            w0[t] = W0[k * NB + j];
+            w1[t] = W1p[k * NB + j];
+            l10[t] = S[(size_t)(c0 + j) * ld + c0 + NB + k]; // L(c0 + 64 + k, c0 + j); unused (finite padding) when nbg == 1
+        }
     }
     const int zc = c0 + (tid < ncg ? tid : 0);
     T zv = S[(size_t)(zc < ncols ? zc : c0) * ld + zrow];
-    if (tid < 2 * NB) zs[tid] = (tid < ncg && c0 + tid < ncols) ? zv : (T)0;
+    if (tid < 2 * NB) zs[tid] = (role == 0 && tid < ncg && c0 + tid < ncols) ? zv : (T)0; // (the helper starts from zero)
     // elimination of the later groups: thread (j2, h) sums half h of the 128 rows of column j2
     const int j2 = tid & 127, h = tid >> 7;
     T lpre[NB];
@@ -1110,9 +1117,12 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 #pragma unroll
         for (int t = 0; t < NB; t++) lpre[t] = col[t];
     };
-    if (G - 1 > g) load_L(G - 1);
+    // this workgroup's later groups: qg = qtop, qtop - 2, ... > g, with (qg - g) odd for the main one, even for the helper
+    const int want = role == 0 ? 1 : 0;
+    const int qtop = (((G - 1 - g) & 1) == want) ? G - 1 : G - 2;
+    if (qtop > g) load_L(qtop);
     __syncthreads();
-    for (int qg = G - 1; qg > g; qg--) {
+    for (int qg = qtop; qg > g; qg -= 2) {
         const int r0 = (odd ? 2 * qg - 1 : 2 * qg) * NB;
         if (tid < 2 * NB) {
             T xv = (T)0;
@@ -1130,11 +1140,24 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 #pragma unroll
         for (int t = 0; t < NB; t++) a += lpre[t] * xin[NB * h + t];
         part2[h][j2] = a;
-        if (qg - 1 > g) load_L(qg - 1); // the next group's block is in flight while this one is reduced and the next x awaited
+        if (qg - 2 > g) load_L(qg - 2); // the next block is in flight while this one is reduced and the next x awaited
         __syncthreads();
         if (tid < 2 * NB) zs[tid] -= part2[0][tid] + part2[1][tid];
         __syncthreads();
     }
+    if (role == 1) { // hand the partial sums to the main workgroup and leave
+        if (tid < ncg) __hip_atomic_store(&zh[c0 + tid], zs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (tid < ncg) {
+        T hv;
+        int spins = 0;
+        do hv = __hip_atomic_load(&zh[c0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (ba_is_sentinel(hv) && ++spins < spin_limit);
+        if (ba_is_sentinel(hv) && errw) __hip_atomic_store(errw, (T)BA_DEVERR_SWEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        zs[tid] += hv;
+    }
+    __syncthreads();
     // the group's own unknowns: x1 = W1^T z1;  z0 -= L10^T x1;  x0 = W0^T z0
     T a = 0;
     if (nbg == 2) {
@@ -1166,15 +1189,19 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x);
 
 // max_groups: how many workgroups of k_ldlt_backflow are certainly resident at once (one per CU is a safe count; they
-// wait for each other, so a grid beyond that falls back to a launch per pair of block columns).
+// wait for each other, so a grid beyond that -- two workgroups per group -- falls back to a launch per pair of block columns).
+// zh: room for 128 scalars per group (the helpers' partial sums), armed with the sentinel like x.
 template <typename T, int NB>
-inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, bool armed = false, int max_groups = 256,
+inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, T *zh, bool armed = false, int max_groups = 256,
                               T *errw = nullptr)
 {
     const int nblk = (ncols + NB - 1) / NB, groups = (nblk + 1) / 2;
-    if (groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
-    if (!armed) hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
-    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x, errw, (int)BA_SWEEP_SPINS);
+    if (2 * groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
+    if (!armed) {
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((groups * 2 * NB + 255) / 256), dim3(256), 0, st, groups * 2 * NB, zh);
+    }
+    hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(2 * groups), dim3(256), 0, st, ncols, ld, zrow, nblk, S, Winv, x, zh, errw, (int)BA_SWEEP_SPINS);
 }
 
 // Host side of the factorisation on `st`: one k_ldlt_panel launch for the first block column, then one fused k_ldlt_step per

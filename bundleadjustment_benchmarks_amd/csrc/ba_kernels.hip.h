@@ -873,7 +873,10 @@ __global__ __launch_bounds__(256) void k_post_reduce(int D, int Dp, int ld, cons
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= Dp) return;
     T *col = S + (size_t)c * ld;
-    if (lane == 0) xarm[c] = ba_sentinel<T>(); // the solution vector of the backward sweep (k_ldlt_backflow polls it entry by entry)
+    if (lane == 0) { // the solution vector of the backward sweep and its helpers' hand-over vector behind it (k_ldlt_backflow polls them entry by entry)
+        xarm[c] = ba_sentinel<T>();
+        xarm[Dp + c] = ba_sentinel<T>();
+    }
     if (c < D) {
         if (lane == 0) {
             col[c] += *lam;

@@ -325,7 +325,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
-        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)4 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)Dp); AL(d_dxp, 3 * M1);
+        AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)4 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)2 * Dp + 2 * NB); /* the solution + the back sweep's hand-over vector */ AL(d_dxp, 3 * M1);
         if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
         AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
@@ -528,7 +528,7 @@ template <typename T> struct Solver final : SolverBase {
     void launch_factor() { ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR); }
 
     // backward sweep: one data-flow launch (k_ldlt_backflow) while its groups are certainly co-resident
-    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR); }
+    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, d_dxc.p + Dp, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR); }
 
     void launch_post_reduce()
     {
@@ -975,9 +975,9 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (which != 1) return BA_ERR_ARG;
         const int nblk = (D + NB - 1) / NB, groups = (nblk + 1) / 2;
-        if (groups < 2 || groups > num_cus) return BA_ERR_ARG;
-        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((Dp + 255) / 256), dim3(256), 0, st, Dp, d_dxc.p);
-        hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(groups), dim3(256), 0, st, D, ld, D, nblk, d_S.p, d_Winv.p, d_dxc.p,
+        if (groups < 2 || 2 * groups > num_cus) return BA_ERR_ARG;
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((2 * Dp + 2 * NB + 255) / 256), dim3(256), 0, st, 2 * Dp + 2 * NB, d_dxc.p);
+        hipLaunchKernelGGL((k_ldlt_backflow<T, NB>), dim3(2 * groups), dim3(256), 0, st, D, ld, D, nblk, d_S.p, d_Winv.p, d_dxc.p, d_dxc.p + Dp,
                            d_scal.p + SC_ERR, 1 << 10, groups - 1);
         have_step = false;
         return fetch_scalars();

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
     long long *stamps;
     CK(hipMalloc(&S, sizeof(double) * h.size())); CK(hipMalloc(&S0, sizeof(double) * h.size()));
     CK(hipMalloc(&Wp, sizeof(double) * (size_t)4 * ld * NB)); CK(hipMalloc(&Winv, sizeof(double) * (size_t)(Dp / NB) * NB * NB));
-    CK(hipMalloc(&x, sizeof(double) * Dp)); CK(hipMalloc(&stamps, 8 * 64));
+    CK(hipMalloc(&x, sizeof(double) * (2 * Dp + 128))); CK(hipMalloc(&stamps, 8 * 64));
     CK(hipMemcpy(S0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     CK(hipMemset(Wp, 0, sizeof(double) * (size_t)4 * ld * NB));
     const int nflags = Dp / NB + 2; CK(hipMalloc(&flags, sizeof(int) * nflags)); CK(hipMemset(flags, 0, sizeof(int) * nflags));
@@ -58,7 +58,7 @@ int main(int argc, char **argv)
             }
         }
         CK(hipEventRecord(e1, st));
-        if (fused) ba_ldlt_backsweep<double, NB>(st, ncols, ld, D, S, Winv, x);
+        if (fused) ba_ldlt_backsweep<double, NB>(st, ncols, ld, D, S, Winv, x, x + Dp);
         else for (int p = nblk - 1; p >= 0; p--) { // one block column per launch
             const int p0 = p * NB;
             int g = (p0 + 63) / 64; if (g < 1) g = 1;
