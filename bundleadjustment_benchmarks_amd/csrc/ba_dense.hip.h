@@ -188,11 +188,14 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     BA_STAMP_PRO0
     // Tile fills: all global loads of a fill are issued before the first LDS store (a load -> store loop pays the L2 round
     // trip once per iteration: 16 x ~800 cycles for one 64 x 64 tile).
-    constexpr int NF = NB * NB / 256;
+    // Only the ten lower 16 x 16 tiles are brought in (the strictly upper tiles of Ad are never read; the diagonal tiles are
+    // mirrored into full ones): 20 KB per workgroup instead of 32 -- every panel workgroup pulls its own copy through one CU.
+    constexpr int NF = 10;
     T fa[NF];
 #pragma unroll
     for (int it = 0; it < NF; it++) {
-        const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
+        constexpr int TI[NF] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TJ[NF] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+        const int r = 16 * TI[it] + (tid & 15), c = 16 * TJ[it] + (tid >> 4);
         fa[it] = S[(size_t)(p0 + min(r, c)) * ld + p0 + max(r, c)]; // mirror the lower triangle
     }
     // operands of the first look-ahead tiles (see below): requested together with the fill, used behind its barrier
@@ -215,7 +218,8 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     typedef typename ba_acc<T>::type acc_t;
 #pragma unroll
     for (int it = 0; it < NF; it++) {
-        const int idx = tid + 256 * it, r = idx % NB, c = idx / NB;
+        constexpr int TI[NF] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TJ[NF] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+        const int r = 16 * TI[it] + (tid & 15), c = 16 * TJ[it] + (tid >> 4);
         Ad[c][r] = fa[it];
         // (W's image needs no clearing: every entry that is read -- the lower tiles and the full diagonal tiles -- is written first)
     }
