@@ -201,7 +201,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
     // operands of the first look-ahead tiles (see below): requested together with the fill, used behind its barrier
     // (only in the one-workgroup-per-CU variant: the 64 registers would push the other one over 256 = one wave per SIMD)
     T t16a[NB / 4], t16b[NB / 4];
-    if (INL && Wprev && wv < 2) {
+    if (INL && Wprev && wv < 1) {
         // (addresses by pointer increments: one 64-bit multiply per operand instead of one per load -- v_mad_i64_i32 is slow, and
         // these sit in front of the first loads of the kernel)
         const T *pa = S + (size_t)(p0 - NB + lk) * ld + p0 + li, *pb = Wprev + (size_t)lk * ld + p0 + 16 * wv + li;
@@ -256,10 +256,11 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
         tile16_load(ti, tj, a, b);
         tile16_apply(ti, tj, a, b);
     };
-    if (Wprev && wv < 2) {
+    if (Wprev && wv < 1) { // (tile (1, 0) follows on wave 1 under the first pivot loop: nobody reads it before the barrier behind A1(0),
+                           // and its 16 KB of operands no longer compete with the block fill for the CU's memory pipe)
         if (!INL) tile16_load(wv, 0, t16a, t16b);
         tile16_apply(wv, 0, t16a, t16b);
-        ba_wave_lds_order(); // wave 0 reads its own tile in A1(0); nobody reads tile (1, 0) before the barrier behind A1(0)
+        ba_wave_lds_order(); // wave 0 reads its own tile in A1(0)
     }
     BA_STAMP_PRO
     // INL (the variant whose rows are updated by other workgroups): TWO panel workgroups per 64-row block, 32 rows each -- the
@@ -419,6 +420,7 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
             // (The inverse rides on wave 0.)  Under the second pivot loop this wave takes the deferred rank-16 updates of the
             // tiles that get no look-ahead update in that phase -- (2,1), (3,2), (3,3) -- which leaves waves 2 and 3 one
             // rank-16 update + one look-ahead tile each.
+            if (s == 0 && Wprev) tile16(1, 0);
             if (s == 1) {
                 a3_tile(0, 16, 1, 0);
                 a3_tile(0, 16, 2, 1);
