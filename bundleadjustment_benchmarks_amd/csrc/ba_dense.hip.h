@@ -1248,7 +1248,10 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
             if (!k128) {
                 const int nq = below > 0 ? npanel : 0;      // workgroups that update the panel workgroups' rows (see k_ldlt_step)
                 const int np2 = below > 0 ? 2 * npanel : 1; // two panel workgroups per 64-row block (32 rows of the row GEMM each)
-                hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), 8192, st, nrows, ncols, ld, p0, np2, S, wcur,
+                // (the first three steps of a 37-block factorisation are update-bound -- 20 us against the 14 us of the panel chain:
+                // there the workgroups may share a CU; 0.545 -> 0.540 ms at D = 2313, and slower again from step 6 on)
+                const unsigned dyn_lds = (p <= 3 && nblk >= 32) ? 0 : 8192;
+                hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), dyn_lds, st, nrows, ncols, ld, p0, np2, S, wcur,
                                    wprev, Winv + (size_t)p * NB * NB, nq, flags, errw);
             } else {
                 // The panels go in pairs (0, 1), (2, 3), ...: an odd step p applies panel p - 1 to the next block column alone (the
