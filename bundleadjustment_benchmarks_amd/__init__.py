@@ -28,7 +28,7 @@ EXPORTS = [
     "ba_minimize", "ba_solver_linearize", "ba_solver_try_step", "ba_solver_accept", "ba_solver_stats", "ba_solver_get",
     "ba_solver_keep_intermediates", "ba_solver_set_state", "ba_solver_timing", "ba_solver_time_phase", "ba_device_info",
     "ba_version", "ba_shard_plan", "ba_problem_save_cache", "ba_problem_load_cache", "ba_solver_selftest",
-    "ba_comm_unique_id", "ba_comm_id_via_file", "ba_solver_comm_init",
+    "ba_comm_unique_id", "ba_comm_id_via_file", "ba_comm_id_file_done", "ba_solver_comm_init", "ba_solver_recoveries",
 ]
 
 
@@ -107,6 +107,8 @@ def lib():
         L.ba_comm_unique_id.argtypes = [C.c_void_p]
         L.ba_comm_id_via_file.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
         L.ba_solver_comm_init.argtypes = [C.c_void_p, C.c_void_p]
+        L.ba_comm_id_file_done.argtypes = [C.c_char_p, C.c_int]
+        L.ba_solver_recoveries.argtypes = [C.c_void_p]
         L.ba_problem_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.ba_problem_get.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.ba_problem_load_bal.argtypes = [C.c_char_p, C.c_void_p]
@@ -288,6 +290,10 @@ class Solver:
         ms = C.c_double()
         _chk(lib().ba_solver_time_phase(self._h, phase, reps, float(lam), C.byref(ms)), "ba_solver_time_phase")
         return ms.value
+
+    def recoveries(self):
+        """Trials ba_minimize repeated through the launch-per-step factorisation after a hand-off time-out."""
+        return int(lib().ba_solver_recoveries(self._h))
 
     def selftest(self, which):
         """Returns the library's return code (not raised): the failure paths are what this hook exists to show."""

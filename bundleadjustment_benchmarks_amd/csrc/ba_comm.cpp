@@ -14,6 +14,10 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <unistd.h>
@@ -104,31 +108,73 @@ int ba_comm_unique_id(void *id_out)
 }
 
 // Rendezvous through a file for processes started by hand (the executables with BA_WORLD / BA_RANK): rank 0 creates the id and
-// publishes it with an atomic rename, the others wait for the file (60 s).
+// publishes it with an atomic rename, the others wait for the file (60 s).  File = the 128-byte id + an 8-byte launch nonce (a hash
+// of the environment variable BA_COMM_NONCE; 0 when unset).
+// A file left behind by an earlier run must never be taken for this run's: rank 0 removes whatever is there before it creates the
+// id and removes its own file again once the communicator stands (ba_comm_id_file_done: ncclCommInitRank is collective, every rank
+// has read the id by then), so a stale file only survives a run that died in between.  A reader refuses a file whose nonce is not
+// its own and -- without a nonce -- one that was written more than two seconds before the reader itself started; it keeps
+// polling until rank 0 has replaced it.  The temporary file is created with O_CREAT | O_EXCL | O_NOFOLLOW, mode 0600.
+static unsigned long long ba_comm_nonce()
+{
+    const char *e = getenv("BA_COMM_NONCE");
+    if (!e || !*e) return 0;
+    unsigned long long h = 1469598103934665603ull; // FNV-1a
+    for (; *e; e++) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+
 int ba_comm_id_via_file(const char *path, int rank, void *id_out)
 {
     if (!path || !id_out || rank < 0) return BA_ERR_ARG;
+    const unsigned long long nonce = ba_comm_nonce();
     if (rank == 0) {
+        (void)unlink(path); // an earlier run's id
         int rc = ba_comm_unique_id(id_out);
         if (rc) return rc;
         const std::string tmp = std::string(path) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f) return BA_ERR_FILE;
-        const bool ok = fwrite(id_out, 1, BA_COMM_ID_BYTES, f) == BA_COMM_ID_BYTES;
-        fclose(f);
-        if (!ok || rename(tmp.c_str(), path) != 0) return BA_ERR_FILE;
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0) return BA_ERR_FILE;
+        unsigned char buf[BA_COMM_ID_BYTES + 8];
+        memcpy(buf, id_out, BA_COMM_ID_BYTES);
+        memcpy(buf + BA_COMM_ID_BYTES, &nonce, 8);
+        const bool ok = write(fd, buf, sizeof buf) == (ssize_t)sizeof buf;
+        (void)close(fd);
+        if (!ok || rename(tmp.c_str(), path) != 0) { (void)unlink(tmp.c_str()); return BA_ERR_FILE; }
         return BA_OK;
     }
+    struct timespec t0;
+    clock_gettime(CLOCK_REALTIME, &t0);
     for (int tries = 0; tries < 600; tries++) {
-        FILE *f = fopen(path, "rb");
-        if (f) {
-            const size_t got = fread(id_out, 1, BA_COMM_ID_BYTES, f);
-            fclose(f);
-            if (got == BA_COMM_ID_BYTES) return BA_OK;
+        const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        if (fd >= 0) {
+            unsigned char buf[BA_COMM_ID_BYTES + 8];
+            struct stat sb;
+            const bool got = fstat(fd, &sb) == 0 && read(fd, buf, sizeof buf) == (ssize_t)sizeof buf;
+            (void)close(fd);
+            if (got) {
+                unsigned long long fn = 0;
+                memcpy(&fn, buf + BA_COMM_ID_BYTES, 8);
+                const double age_at_start = (double)(t0.tv_sec - sb.st_mtim.tv_sec) + 1e-9 * (double)(t0.tv_nsec - sb.st_mtim.tv_nsec);
+                if (fn == nonce && (nonce != 0 || age_at_start < 2.0)) {
+                    memcpy(id_out, buf, BA_COMM_ID_BYTES);
+                    return BA_OK;
+                }
+            }
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
+    fprintf(stderr, "ba_mi355x: no communicator id appeared in %s within 60 s (rank %d)\n", path, rank);
     return BA_ERR_COMM;
+}
+
+// Call after ba_solver_comm_init has returned (collective): rank 0 removes the rendezvous file, the others do nothing.
+int ba_comm_id_file_done(const char *path, int rank)
+{
+    if (!path || rank < 0) return BA_ERR_ARG;
+    if (rank == 0) (void)unlink(path);
+    return BA_OK;
 }
 
 } // extern "C"

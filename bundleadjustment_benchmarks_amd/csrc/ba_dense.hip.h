@@ -50,9 +50,7 @@ __device__ __forceinline__ float ba_rcp(float d)
 // Bounds of the in-launch hand-off waits (a wait that runs out is an ERROR, reported through the device error word).
 #define BA_FLAG_SPINS (1 << 22)
 #define BA_SWEEP_SPINS (1 << 24)
-#define BA_DEVERR_ROW_FLAG 1 /* k_ldlt_step: a panel workgroup never saw its rows' look-ahead update announced */
-#define BA_DEVERR_SWEEP 2    /* k_ldlt_backflow: an unknown of a later group was never published */
-
+// (BA_DEVERR_*: ba_mfma.hip.h)
 // compile-time list of (up to four) tile indices
 template <int N, int T0, int T1, int T2, int T3> struct ba_tiles {
     static constexpr int n = N;
@@ -172,7 +170,7 @@ template <typename T, int NB, bool INL>
 __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int p0, T *__restrict__ S, T *__restrict__ Wp,
                                               T *__restrict__ Winv, const T *__restrict__ Wprev, int blk, int nblk_panel,
                                               T (&Ad)[NB][NB + 1], T (&Wl)[NB][NB + 1], const int *flags = nullptr, int epoch = 0,
-                                              T *errw = nullptr)
+                                              T *errw = nullptr, int fault = 0 /* self-test: a short wait for an announcement that never comes */)
 {
     static_assert(NB == 64, "the panel kernel is written for 64-wide block columns");
     // Ad: diagonal block, Ad[col][row]; lower tiles + full diagonal tiles are maintained.  Wl: W[row][col].  Both are declared by
@@ -459,13 +457,14 @@ __device__ __forceinline__ void ba_panel_body(int nrows, int ncols, int ld, int 
                 // finished long ago; a wave with time to spare makes sure here, so that the L2 round trip of the check is not
                 // in front of the row GEMM -- every wave reads the rows behind the barriers that follow
                 int spins = 0;
-                while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < BA_FLAG_SPINS)
+                const int spin_limit = fault ? (1 << 8) : BA_FLAG_SPINS;
+                while (__hip_atomic_load(&flags[rown / NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < spin_limit)
                     __builtin_amdgcn_s_sleep(4);
                 // pairs with the release store of the row workgroup (k_ldlt_step): its rows are visible behind this fence
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 // A wait that ran out means the row GEMM below would read rows without their update: the factor would be finite
                 // and wrong.  Loud instead: the error word travels to the host with the scalars of the trial (BA_ERR_HIP).
-                if (spins >= BA_FLAG_SPINS && errw) __hip_atomic_store(errw, (T)BA_DEVERR_ROW_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins >= spin_limit && errw) __hip_atomic_store(errw, (T)BA_DEVERR_ROW_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (s == 3) {
                 // ... and the sums of row 3, which do not need W_33 (being built by wave 1 right now): only the three
@@ -656,7 +655,7 @@ template <typename T> struct ba_macro_job { const T *W1, *W2; int pM, base, coun
 template <typename T, int NB, bool INL, bool MACRO>
 __device__ __forceinline__ void ba_step_body(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S, T *__restrict__ Wp,
                                              const T *__restrict__ Wprev, T *__restrict__ Winv, int nq, int *__restrict__ flags,
-                                             T *__restrict__ errw, int upd_mode, int n64, const ba_macro_job<T> &mj)
+                                             T *__restrict__ errw, int upd_mode, int n64, const ba_macro_job<T> &mj, int fault)
 {
     __shared__ T Ad[NB][NB + 1], Wl[NB][NB + 1];
     int bid = blockIdx.x;
@@ -666,12 +665,12 @@ __device__ __forceinline__ void ba_step_body(int nrows, int ncols, int ld, int p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left
         __syncthreads();
         // release: the tile's (write-through) stores of every wave, ordered by the barrier above, are visible at agent scope before the flag
-        if (threadIdx.x == 0) __hip_atomic_store(&flags[rown / NB], p0 / NB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && !fault) __hip_atomic_store(&flags[rown / NB], p0 / NB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (INL) bid -= nq;
     if (bid < npanel) {
-        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, Ad, Wl, INL ? flags : nullptr, p0 / NB, errw);
+        ba_panel_body<T, NB, INL>(nrows, ncols, ld, p0, S, Wp, Winv, Wprev, bid, npanel, Ad, Wl, INL ? flags : nullptr, p0 / NB, errw, fault);
         return;
     }
     // Trailing update by the workgroups behind the panel workgroups.  First n64 workgroups with 64 x 64 tiles and panel p - 1 alone:
@@ -713,10 +712,10 @@ __device__ __forceinline__ void ba_step_body(int nrows, int ncols, int ld, int p
 template <typename T, int NB, bool INL>
 __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S,
                                                    T *__restrict__ Wp, const T *__restrict__ Wprev, T *__restrict__ Winv,
-                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr)
+                                                   int nq = 0, int *__restrict__ flags = nullptr, T *__restrict__ errw = nullptr, int fault = 0)
 {
     static_assert(INL, "the two-per-CU variant is k_ldlt_step2");
-    ba_step_body<T, NB, true, false>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, 0, 1 << 30, ba_macro_job<T>{});
+    ba_step_body<T, NB, true, false>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, 0, 1 << 30, ba_macro_job<T>{}, fault);
 }
 
 // The two-workgroups-per-CU variant for update-bound sizes (no dynamic-LDS request): the same panel structure -- row workgroups in
@@ -727,9 +726,9 @@ __global__ __launch_bounds__(256) void k_ldlt_step(int nrows, int ncols, int ld,
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void k_ldlt_step2(int nrows, int ncols, int ld, int p0, int npanel, T *__restrict__ S, T *__restrict__ Wp,
                                                     const T *__restrict__ Wprev, T *__restrict__ Winv, int nq, int *__restrict__ flags,
-                                                    T *__restrict__ errw, int upd_mode, int n64, ba_macro_job<T> mj)
+                                                    T *__restrict__ errw, int upd_mode, int n64, ba_macro_job<T> mj, int fault = 0)
 {
-    ba_step_body<T, NB, true, true>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, upd_mode, n64, mj);
+    ba_step_body<T, NB, true, true>(nrows, ncols, ld, p0, npanel, S, Wp, Wprev, Winv, nq, flags, errw, upd_mode, n64, mj, fault);
 }
 
 // Trailing update of one 64 x 64 tile with the 64-wide panel at block column p0: C_ij -= sum_k Y_ik L_jk.
@@ -1199,10 +1198,10 @@ template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t
 // zh: room for 128 scalars per group (the helpers' partial sums), armed with the sentinel like x.
 template <typename T, int NB>
 inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, T *zh, bool armed = false, int max_groups = 256,
-                              T *errw = nullptr)
+                              T *errw = nullptr, bool safe = false)
 {
     const int nblk = (ncols + NB - 1) / NB, groups = (nblk + 1) / 2;
-    if (2 * groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
+    if (safe || 2 * groups > max_groups) { ba_ldlt_backsweep_launches<T, NB>(st, ncols, ld, zrow, S, Winv, x); return; }
     if (!armed) {
         hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, x);
         hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((groups * 2 * NB + 255) / 256), dim3(256), 0, st, groups * 2 * NB, zh);
@@ -1213,8 +1212,11 @@ inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S,
 // Host side of the factorisation on `st`: one k_ldlt_panel launch for the first block column, then one fused k_ldlt_step per
 // block column (or panel + update launches for a single block column).  flags: nflags ints (hand-off flags of the row
 // workgroups), Wp: 2 * ld * NB (double-buffered Y = L D panel), Winv: one NB x NB inverse per block column.
+// safe: panel + update launches per block column (no workgroup waits for another one of its launch) -- the retry path after a
+// hand-off time-out; fault: self-test, the row workgroups of the fused steps stay silent.
 template <typename T, int NB>
-inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr)
+inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr,
+                           bool safe = false, int fault = 0)
 {
     const int nblk = (ncols + NB - 1) / NB;
     const size_t wsz = (size_t)ld * NB;
@@ -1227,7 +1229,7 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
         T *wcur = Wp + (size_t)(k128 ? p % 4 : (p & 1)) * wsz, *wprev = Wp + (size_t)(k128 ? (p + 3) % 4 : ((p + 1) & 1)) * wsz;
         // The fused look-ahead step wins at every size (dense bench, D = 100 ... 9216): it saves a launch per block column
         // and keeps the previous panel's update off the diagonal block's path.
-        const bool fused = nblk >= 2;
+        const bool fused = nblk >= 2 && !safe;
         if (p == 0 || !fused) {
             hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, S, fused ? wcur : Wp,
                                Winv + (size_t)p * NB * NB, flags, nflags);
@@ -1252,7 +1254,7 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
                 // there the workgroups may share a CU; 0.545 -> 0.540 ms at D = 2313, and slower again from step 6 on)
                 const unsigned dyn_lds = (p <= 3 && nblk >= 32) ? 0 : 8192;
                 hipLaunchKernelGGL((k_ldlt_step<T, NB, true>), dim3(nq + np2 + nupd), dim3(256), dyn_lds, st, nrows, ncols, ld, p0, np2, S, wcur,
-                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw);
+                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, fault);
             } else {
                 // The panels go in pairs (0, 1), (2, 3), ...: an odd step p applies panel p - 1 to the next block column alone (the
                 // one step p + 1 factors), the even step p + 1 applies the pair (p - 1, p) to everything from block column p + 2 on
@@ -1279,7 +1281,7 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
                 } else mj = {Wp + (size_t)((p - 2) % 4) * wsz, wprev, p0 - 2 * NB, p0 + NB, macro_count(p0 + NB)};
                 const int nq = below > 0 ? npanel : 0, np2 = below > 0 ? 2 * npanel : 1;
                 hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64 + mj.count), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
-                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, mj);
+                                   wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, mj, fault);
             }
         }
     }

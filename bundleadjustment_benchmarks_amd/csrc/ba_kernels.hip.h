@@ -1066,12 +1066,17 @@ template <typename T> struct ba_lm_dev {
     long long t_ctl, t_end;
     int timed;   // t_ctl / t_end describe the iteration just before this one (not the host-synchronous first linearisation)
     int prev_go; // ... and that iteration linearised
+    int prev_code; // decision of the previous trial (accepted + 2 stop): what this shard put into the guard slot of the scalar all-reduce
 };
 // trial_ticks: t_ctl - previous t_end (elimination ... test energy); ctl_ticks_prev: the control segment (control, x = xTest,
 // linearisation) that preceded this trial; both < 0 when unknown
-struct ba_lm_row { double iter, accepted, f, rho, lambda, lambda_used, e_test, dx_norm, trial_ticks, ctl_ticks_prev, prev_go; };
+// stop: 0 = the run goes on behind this row, 1 = this row ended it (the host enqueues trial n only when row n - LM_DEPTH carries
+// stop == 0: the number of trials -- and of collectives -- a rank enqueues depends on device data alone), 2 = ended by a device
+// error: the row is not part of the table
+struct ba_lm_row { double iter, accepted, f, rho, lambda, lambda_used, e_test, dx_norm, trial_ticks, ctl_ticks_prev, prev_go, stop; };
 struct ba_lm_host { int done, stop, status, pad; ba_lm_row rows[BA_LM_RING]; };
-struct ba_lm_slots { int energy, etest, rho_p, rho_c, dn_p, dn_c, lambda, err; }; // indices into scal[]
+// indices into scal[]; guard: the slot that rides on the scalar all-reduce with every shard's previous decision (world = summands)
+struct ba_lm_slots { int energy, etest, rho_p, rho_c, dn_p, dn_c, lambda, err, guard, world; };
 
 template <typename T>
 __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_dev<T> *__restrict__ lm, ba_lm_host *__restrict__ host, ba_lm_slots sl)
@@ -1102,9 +1107,20 @@ __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_d
     s.timed = 1;
     row.iter = s.iter; row.f = (double)s.energy; row.lambda_used = (double)lam_used; row.e_test = (double)e_test; row.dx_norm = sqrt((double)dn);
     int go = 0;
-    if (scal[sl.err] != (T)0) { // a hand-off wait ran out inside this trial (ba_dense.hip.h): the step is garbage, stop loudly
-        s.deverr = (int)scal[sl.err];
-        scal[sl.err] = 0;
+    bool failed = false;
+    if (scal[sl.guard] != (T)(sl.world * s.prev_code)) { // sharded: the decisions of the previous trial, summed over the shards, are
+        // not `world` times this shard's -- the shards have parted (they run the same control on the same all-reduced scalars, so
+        // this cannot happen unless a transport hands different sums to different ranks); stop loudly instead of drifting apart
+        s.deverr = BA_DEVERR_DIVERGED;
+        failed = true;
+    } else if (scal[sl.err] != (T)0) { // a hand-off wait ran out inside this trial (ba_dense.hip.h): the step is garbage, stop loudly
+        // (sharded: the SUM of the shards' error words -- it rides on the scalar all-reduce, so every shard stops on the same trial;
+        // BA_DEVERR_ROW_FLAG counts in the low ten bits, BA_DEVERR_SWEEP above them)
+        s.deverr = scal[sl.err] >= (T)BA_DEVERR_SWEEP ? BA_DEVERR_SWEEP : BA_DEVERR_ROW_FLAG;
+        failed = true;
+    }
+    scal[sl.err] = 0;
+    if (failed) {
         s.status = BA_DEV_FAILED;
         s.stop = 1;
         row.accepted = 0; row.rho = 0; row.lambda = (double)s.lambda;
@@ -1142,13 +1158,23 @@ __global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_d
     if (!s.stop && s.max_trials > 0 && s.trials >= s.max_trials) { s.stop = 1; s.status = -1; } // the max_trials extension: Running
     s.go = go;
     s.prev_go = go;
+    s.prev_code = (row.accepted != 0 ? 1 : 0) + 2 * (s.stop != 0 ? 1 : 0);
+    scal[sl.guard] = (T)s.prev_code;
     scal[sl.lambda] = s.lambda;
+    row.stop = failed ? 2.0 : (s.stop ? 1.0 : 0.0);
     *lm = s;
     host->rows[t % BA_LM_RING] = row;
     host->stop = s.stop;
     host->status = s.status;
     __threadfence_system();
     __hip_atomic_store(&host->done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Self-test only (ba_solver_selftest(3)): keeps the stream busy for `ticks` of the 100 MHz wall clock, then ends by itself.
+__global__ void k_spin(long long ticks)
+{
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 // x = xTest (BacktrackLevMarqQRChol.h:428), when the control kernel said so (go == nullptr: unconditionally, ba_solver_accept).

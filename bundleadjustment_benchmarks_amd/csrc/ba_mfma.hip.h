@@ -8,6 +8,13 @@
 
 #include <hip/hip_runtime.h>
 
+// Device error word (one scalar slot of the solver): written by a kernel whose bounded in-launch hand-off wait ran out.
+#define BA_DEVERR_ROW_FLAG 1 /* k_ldlt_step: a panel workgroup never saw its rows' look-ahead update announced */
+#define BA_DEVERR_SWEEP 1024 /* k_ldlt_backflow: an unknown of a later group was never published (the error words of the shards are SUMMED by the
+                                scalar all-reduce: row-flag time-outs count below 1024, this one above) */
+
+#define BA_DEVERR_DIVERGED 3 /* k_lm_control: the shards of a sharded solve did not take the same accept / stop decision */
+
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
 typedef float ba_f4 __attribute__((ext_vector_type(4)));
 

@@ -34,12 +34,17 @@ namespace {
 
 constexpr int NB = BA_NB;    // block-column width of the dense LDL^T
 constexpr int NAUG = 3;      // augmented rows: D = reduced rhs, D+1 = g_c, D+2 = spare
-constexpr int NSCAL = 16;    // device scalar slots
-enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4, SC_RHO_C = 5, SC_DN_C = 6, SC_DMAX_C = 7,
-       SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
+constexpr int NSCAL = 24;    // device scalar slots
+// SC_ETEST .. SC_ERR are contiguous: the ONE scalar all-reduce behind a sharded trial sums these five
+enum { SC_ENERGY = 0, SC_DMAX_P = 1, SC_ETEST = 2, SC_RHO_P = 3, SC_DN_P = 4,
+       SC_GUARD = 5 /* the previous trial's decision (accepted + 2 stop) of this shard: summed, it must be world x the same (k_lm_control) */,
+       SC_ERR = 6 /* device error word: a BA_DEVERR_* code written by a kernel whose in-launch hand-off wait ran out (sharded: summed, so
+                     that every shard sees a time-out of any shard on the same trial) */,
+       SC_DMAX_C = 7, SC_ST0 = 8 /* ..11 stats */, SC_LAMBDA = 12 /* lambda of the current trial, read by the kernels */,
        SC_ZERO = 13 /* always 0: the 'lambda' of MOREQR's outer factorisation */,
-       SC_ERR = 14 /* device error word: a BA_DEVERR_* code written by a kernel whose in-launch hand-off wait ran out */,
-       SC_ELOC = 15 /* sharded: this shard's part of the energy of the latest linearisation (rides on the next packed all-reduce) */ };
+       SC_ELOC = 15 /* sharded: this shard's part of the energy of the latest linearisation (rides on the next packed all-reduce) */,
+       SC_RHO_C = 16, SC_DN_C = 17 };
+constexpr int N_STEP_SCALARS = 5; // SC_ETEST, SC_RHO_P, SC_DN_P, SC_GUARD, SC_ERR
 enum { EV_T0 = 0, EV_T1, EV_T2, EV_T3, EV_T4, EV_T5, EV_T6, EV_L0, EV_L1, EV_N };
 constexpr int RING_EV = 8; // event slots of the trials in flight under ba_minimize (LM_DEPTH + the ones not yet harvested)
 constexpr int RING_NE = 6; // per slot: trial start | before / after the matrix all-reduce | before / after the scalar all-reduce | after control + linearisation
@@ -78,6 +83,8 @@ struct SolverBase {
     virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
     virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
     virtual int selftest(int which) = 0;
+    bool poisoned = false; // the watchdog gave up on a launch that never finished: every later call fails, nothing is freed
+    int recoveries = 0;    // trials repeated through the launch-per-step factorisation after a hand-off time-out
     ba_allreduce_fn ar_fn = nullptr;
     void *ar_user = nullptr;
     void *comm = nullptr; // ncclComm_t of the shard group (ba_solver_comm_init)
@@ -149,9 +156,16 @@ template <typename T> struct Solver final : SolverBase {
     bool have_step = false;
     int num_cus = 256; // of the device the solver lives on
     double wall_khz = 1e5;
+    // A hand-off between workgroups of one launch that timed out (device error word) is survivable: the trial is repeated with the
+    // factorisation and the back sweep as one launch per step (nobody waits for anybody), and the solver stays in that mode.
+    bool safe_factor = false;
+    int fault_rowflag = 0;    // self-test (2): the fused steps' row workgroups stay silent, the panel's wait is short
+    double spin_next_s = 0;   // self-test (3): a kernel of that many seconds in front of the next trial
+    double watchdog_s = 600;  // no LM row for that long = a hung launch (BA_WATCHDOG_S)
 
     ~Solver() override
     {
+        if (poisoned) return; // (ba_solver_free does not even get here: a HIP call could block on the launch that never ended)
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
         for (auto &sl : ring)
@@ -191,6 +205,7 @@ template <typename T> struct Solver final : SolverBase {
         memset((void *)h_log, 0, sizeof(ba_lm_host));
         HIPCHK(hipHostGetDevicePointer((void **)&d_log, (void *)h_log, 0));
         use_graph = getenv("BA_NO_GRAPH") == nullptr;
+        if (const char *wd = getenv("BA_WATCHDOG_S")) { const double v = atof(wd); if (v > 0) watchdog_s = v; }
         {
             int dev = 0;
             hipDeviceProp_t pr;
@@ -372,8 +387,9 @@ template <typename T> struct Solver final : SolverBase {
     static void report_device_error(int code)
     {
         fprintf(stderr, "ba_mi355x: device error %d: %s\n", code,
-                code == BA_DEVERR_ROW_FLAG ? "k_ldlt_step: the look-ahead update of a row block was never announced"
-                                           : "k_ldlt_backflow: an unknown of the backward sweep was never published");
+                code == BA_DEVERR_DIVERGED ? "k_lm_control: the shards did not take the same accept / stop decision"
+                : code >= BA_DEVERR_SWEEP  ? "k_ldlt_backflow: an unknown of the backward sweep was never published"
+                                           : "k_ldlt_step: the look-ahead update of a row block was never announced");
     }
 
     double ev_ms(hipEvent_t a, hipEvent_t b)
@@ -525,10 +541,18 @@ template <typename T> struct Solver final : SolverBase {
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
 
-    void launch_factor() { ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR); }
+    void launch_factor()
+    {
+        ba_ldlt_factor<T, NB>(st, D + 1, D, ld, d_S.p, d_Wp.p, d_Winv.p, d_flags.p, (int)d_flags.n, d_scal.p + SC_ERR, safe_factor,
+                              safe_factor ? 0 : fault_rowflag);
+    }
 
     // backward sweep: one data-flow launch (k_ldlt_backflow) while its groups are certainly co-resident
-    void launch_backsweep() { ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, d_dxc.p + Dp, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR); }
+    void launch_backsweep()
+    {
+        ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, d_dxc.p + Dp, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR,
+                                 safe_factor);
+    }
 
     void launch_post_reduce()
     {
@@ -602,7 +626,7 @@ template <typename T> struct Solver final : SolverBase {
     // step control on the device, x = xTest and the linearisation of the next outer iteration, the latter two conditional
     int launch_seg_ctl()
     {
-        ba_lm_slots sl{sharded() ? SC_ENERGY : SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR};
+        ba_lm_slots sl{SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR, SC_GUARD, world};
         hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(64), 0, st, d_scal.p, d_lm.p, d_log, sl);
         return linearize_enqueue(false, &d_lm.p->go); // (x = xTest happens inside its first kernel)
     }
@@ -636,7 +660,7 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T5], st));
         launch_test_energy();
         HIPCHK(hipEventRecord(ev[EV_T6], st));
-        if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;
+        if ((rc = allreduce(d_scal.p + SC_ETEST, N_STEP_SCALARS, 0))) return rc; // (the error word too: a time-out of one shard fails the step on all)
         if ((rc = fetch_scalars())) return rc;
         HIPCHK(hipGetLastError());
         tm.eliminate_ms += ev_ms(EV_T0, EV_T1);
@@ -826,6 +850,10 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         EvSlot &e = ring[slot];
+        if (spin_next_s > 0) { // self-test (3): a launch that outlasts the watchdog (it ends by itself)
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, (long long)(spin_next_s * wall_khz * 1e3));
+            spin_next_s = 0;
+        }
         if (!sharded()) // ONE graph per LM iteration and no event between the launches: the times come from the device's wall clock
             return run_seg(&g_trial, &Solver::launch_seg_iter, graphs);
         HIPCHK(hipEventRecord(e.e[0], st));
@@ -836,7 +864,8 @@ template <typename T> struct Solver final : SolverBase {
             HIPCHK(hipEventRecord(e.e[2], st));
             if ((rc = run_seg(&g_b, &Solver::launch_seg_b, graphs))) return rc;
             HIPCHK(hipEventRecord(e.e[3], st));
-            if ((rc = allreduce(d_scal.p + SC_ETEST, 3, 0))) return rc;     // test energy, rho denominator, |dx|^2 (point parts)
+            // test energy, rho denominator, |dx|^2 (point parts) + the guard slot and the error word
+            if ((rc = allreduce(d_scal.p + SC_ETEST, N_STEP_SCALARS, 0))) return rc;
         }
         HIPCHK(hipEventRecord(e.e[4], st));
         if ((rc = run_seg(&g_ctl, &Solver::launch_seg_ctl, graphs))) return rc;
@@ -856,6 +885,7 @@ template <typename T> struct Solver final : SolverBase {
 
     int minimize(const ba_lm_params *lmp, ba_trial_cb cb, void *user, ba_result *out) override
     {
+        if (poisoned) return BA_ERR_HIP;
         ba_lm_params lm;
         if (lmp) lm = *lmp; else ba_lm_params_default(&lm);
         const auto tbeg = std::chrono::steady_clock::now();
@@ -892,6 +922,8 @@ template <typename T> struct Solver final : SolverBase {
         if (!h.stop) {
             h_log->done = 0; h_log->stop = 0; h_log->status = BA_RUNNING;
             if ((rc = set_lambda(h.lambda))) return rc;
+            static_assert(SC_ERR == SC_GUARD + 1, "cleared together");
+            HIPCHK(hipMemsetAsync(d_scal.p + SC_GUARD, 0, 2 * sizeof(T), st)); // the guard slot of trial 0 (no decision yet), no error
             HIPCHK(hipMemcpyAsync(d_lm.p, &h, sizeof h, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st)); // (h is on the stack)
             // graphs unless the stream cannot be captured (legacy stream) or a host callback sits between the segments anyway
@@ -905,6 +937,8 @@ template <typename T> struct Solver final : SolverBase {
                     const double el = std::chrono::duration<double>(tnow - tlast).count();
                     tlast = tnow;
                     acc_of[consumed % RING_EV] = r.accepted != 0;
+                    consumed++;
+                    if (r.stop == 2.0) continue; // ended by a device error: not a row of the table (the trial is repeated or the run fails)
                     if (!sharded()) { // device wall-clock stamps (k_lm_control): no events sit between the launches of an iteration
                         tm.n_graph_trials++;
                         if (r.trial_ticks >= 0) { tm.trial_ms += r.trial_ticks / wall_khz; tm.n_trials++; } // (not the first: host time sits in front of it)
@@ -913,38 +947,93 @@ template <typename T> struct Solver final : SolverBase {
                     if (cb) cb(user, (int)r.iter, (int)r.accepted, r.f, r.rho, r.lambda, el);
                     if (talk) // outputIter, BacktrackLevMarqQRChol.h:84-93 (f is the energy BEFORE the step)
                         printf("%5d%15s%15g%15g%15g%14gs\n", (int)r.iter, r.accepted != 0 ? "Accepted" : "Rejected", r.f, r.rho, r.lambda, el);
-                    consumed++;
                 }
                 while (harvested + 1 < consumed) { if (sharded()) harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; } // (its events are complete)
                 return done;
             };
-            auto tprog = std::chrono::steady_clock::now(); // last time the device made progress (a trial finished)
-            int seen = 0;
-            while (true) {
-                const int done = drain();
-                if (done != seen) { seen = done; tprog = std::chrono::steady_clock::now(); }
-                if (__atomic_load_n(&h_log->stop, __ATOMIC_ACQUIRE)) break;
-                const bool all_in = lm.max_trials > 0 && launched >= lm.max_trials;
-                if (all_in && done >= launched) break; // (the device has set `stop` by then; belt and braces)
-                if (!all_in && launched - done < LM_DEPTH) {
-                    if ((rc = enqueue_trial(launched % RING_EV, graphs))) break;
-                    launched++;
-                    continue;
+            for (int attempt = 0;; attempt++) {
+                // How many trials are enqueued depends on DEVICE DATA ONLY: trial n goes into the stream iff n < LM_DEPTH or row
+                // n - LM_DEPTH has arrived with its stop mark clear (and n < max_trials).  The row that ends the run is row s on
+                // every shard (same control kernel, same all-reduced scalars), so every rank enqueues exactly s + LM_DEPTH trials
+                // and with them the same number of collectives -- whatever its host's timing.  (Looking at a global "stopped"
+                // word instead made that number depend on WHEN a host looked: a rank one trial ahead then sat in ncclAllReduce
+                // for ever.)  Trials behind row s run as no-ops (k_lm_control returns at once, nothing is accepted).
+                auto tprog = std::chrono::steady_clock::now(); // last time the device made progress (a trial finished)
+                int seen = consumed;
+                while (true) {
+                    const int done = drain();
+                    if (done != seen) { seen = done; tprog = std::chrono::steady_clock::now(); }
+                    bool may = !(lm.max_trials > 0 && launched >= lm.max_trials), final = !may;
+                    if (may && launched >= LM_DEPTH) {
+                        const int need = launched - LM_DEPTH;
+                        if (done <= need) may = false;                                                       // (not there yet)
+                        else if (h_log->rows[need % BA_LM_RING].stop != 0.0) { may = false; final = true; }   // the run ended at row `need`
+                    }
+                    if (may) {
+                        if ((rc = enqueue_trial(launched % RING_EV, graphs))) break;
+                        launched++;
+                        continue;
+                    }
+                    if (final) break; // nothing more will ever be enqueued: wait for what is in the stream
+                    // LM_DEPTH trials are in the stream: wait for a row (a trial is 0.1 ... 20 ms; watchdog_s without one = a hung launch)
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tprog).count() > watchdog_s) {
+                        // Nothing can be waited for and nothing freed: the stream holds the launch that never ends (a synchronise or
+                        // a hipFree would block for ever).  The handle is dead from here on; a retry belongs in a fresh process.
+                        fprintf(stderr, "ba_mi355x: no LM trial completed within %g s -- giving up on this solver (nothing is freed)\n", watchdog_s);
+                        poisoned = true;
+                        return BA_ERR_HIP;
+                    }
+                    __builtin_ia32_pause();
                 }
-                // LM_DEPTH trials are in the stream: wait for a row (a trial is 0.1 ... 20 ms; ten minutes without one = a hung kernel)
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tprog).count() > 600.0) {
-                    fprintf(stderr, "ba_mi355x: no LM trial completed within 600 s\n");
-                    rc = BA_ERR_HIP;
-                    break;
+                if (!rc) { // wait for the stream with the same watchdog (a trial enqueued behind the last row may be the one that hangs)
+                    const auto tw = std::chrono::steady_clock::now();
+                    hipError_t eq;
+                    while ((eq = hipStreamQuery(st)) == hipErrorNotReady) {
+                        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > watchdog_s) {
+                            fprintf(stderr, "ba_mi355x: the stream did not drain within %g s -- giving up on this solver (nothing is freed)\n", watchdog_s);
+                            poisoned = true;
+                            return BA_ERR_HIP;
+                        }
+                        __builtin_ia32_pause();
+                    }
+                    if (eq != hipSuccess) { fprintf(stderr, "ba_mi355x: %s\n", hipGetErrorString(eq)); return BA_ERR_HIP; }
+                } else {
+                    const hipError_t es = hipStreamSynchronize(st);
+                    if (es != hipSuccess) { fprintf(stderr, "ba_mi355x: %s\n", hipGetErrorString(es)); return BA_ERR_HIP; }
                 }
-                __builtin_ia32_pause();
+                drain();
+                while (harvested < consumed) { if (sharded()) harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; }
+                if (rc) return rc;
+                HIPCHK(hipMemcpy(&h, d_lm.p, sizeof h, hipMemcpyDeviceToHost));
+                if (h.status != BA_DEV_FAILED) break;
+                report_device_error(h.deverr);
+                if (h.deverr == BA_DEVERR_DIVERGED) return BA_ERR_COMM;
+                if (safe_factor || attempt > 0) return BA_ERR_HIP; // (the launch-per-step path has no hand-offs: cannot happen)
+                // ---- a hand-off inside a fused launch timed out (a row workgroup not resident in time: a GPU shared with another
+                // process, say).  x, lambda and the linearisation are untouched (nothing was accepted); repeat the trial -- and run
+                // the rest -- with one launch per step.  Sharded: the error word rode on the scalar all-reduce, every rank is here.
+                fprintf(stderr, "ba_mi355x: repeating LM trial %d with the launch-per-step factorisation\n", h.trials - 1);
+                safe_factor = true;
+                recoveries++;
+                for (hipGraphExec_t *g : {&g_trial, &g_b})
+                    if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+                h.trials -= 1; h.fun_evals -= 1; // the failed trial's row does not count
+                h.status = BA_RUNNING; h.stop = 0; h.deverr = 0; h.go = 0; h.timed = 0; h.prev_go = 0;
+                // (h.prev_code stays: it is the decision of the last GOOD trial, and that is what the guard slot must carry again)
+                {
+                    const T code = (T)h.prev_code;
+                    *h_lam = code; // (pinned staging word; lambda itself lives on the device)
+                    HIPCHK(hipMemcpyAsync(d_scal.p + SC_GUARD, h_lam, sizeof(T), hipMemcpyHostToDevice, st));
+                    // (the trials that were in the stream behind the failed one ran the same fused launches and raised the word again)
+                    HIPCHK(hipMemsetAsync(d_scal.p + SC_ERR, 0, sizeof(T), st));
+                }
+                HIPCHK(hipMemcpyAsync(d_lm.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                launched = consumed = harvested = h.trials;
+                if (lm.max_trials > 0) { /* rows already delivered count: the device compares s.trials with max_trials itself */ }
+                __atomic_store_n(&h_log->done, h.trials, __ATOMIC_RELEASE);
+                h_log->stop = 0; h_log->status = BA_RUNNING;
             }
-            const hipError_t es = hipStreamSynchronize(st);
-            if (es != hipSuccess) { fprintf(stderr, "ba_mi355x: %s\n", hipGetErrorString(es)); return BA_ERR_HIP; }
-            drain();
-            while (harvested < consumed) { if (sharded()) harvest(harvested % RING_EV, acc_of[harvested % RING_EV]); harvested++; }
-            if (rc) return rc;
-            HIPCHK(hipMemcpy(&h, d_lm.p, sizeof h, hipMemcpyDeviceToHost));
             if (h.fresh) { // stopped (max_trials) right behind an accepted step: the energy of the linearisation that followed it
                 if ((rc = fetch_scalars())) return rc;
                 if (sharded()) { // (only this shard's part is there until a trial carries it through the all-reduce)
@@ -953,7 +1042,6 @@ template <typename T> struct Solver final : SolverBase {
                 }
                 h.energy = h_scal[SC_ENERGY];
             }
-            if (h.status == BA_DEV_FAILED) { report_device_error(h.deverr); return BA_ERR_HIP; }
             HIPCHK(hipGetLastError());
         }
         if (talk) printf("--------------------------------------------------------------------------------\n");
@@ -973,6 +1061,18 @@ template <typename T> struct Solver final : SolverBase {
     // it wait for unknowns that are never published -- the production path's reaction to that must be BA_ERR_HIP.
     int selftest(int which) override
     {
+        if (which == 2) { // arm: the fused factorisation's row workgroups stay silent and the panel's wait is short -- the next
+                          // ba_minimize meets BA_DEVERR_ROW_FLAG on its first trial and must recover through the launch-per-step path
+            if ((D + NB - 1) / NB < 2 || safe_factor) return BA_ERR_ARG; // (a single block column has no fused step)
+            fault_rowflag = 1;
+            for (hipGraphExec_t *g : {&g_trial, &g_b})
+                if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+            return BA_OK;
+        }
+        if (which == 3) { // arm: a 4-second kernel in front of the next trial -- with BA_WATCHDOG_S below that, ba_minimize must give up
+            spin_next_s = 4.0;
+            return BA_OK;
+        }
         if (which != 1) return BA_ERR_ARG;
         const int nblk = (D + NB - 1) / NB, groups = (nblk + 1) / 2;
         if (groups < 2 || 2 * groups > num_cus) return BA_ERR_ARG;
@@ -1089,9 +1189,13 @@ int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar,
 void ba_solver_free(ba_solver *s)
 {
     if (!s) return;
-    delete s->impl;
+    // a solver the watchdog gave up on still has a launch in its stream that may never end: every HIP call that frees or
+    // synchronises could block with it -- its device memory is left to the end of the process
+    if (!s->impl->poisoned) delete s->impl;
     delete s;
 }
+
+int ba_solver_recoveries(const ba_solver *s) { return s ? s->impl->recoveries : -1; }
 
 int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user)
 {
@@ -1110,6 +1214,7 @@ int ba_solver_comm_init(ba_solver *s, const void *id)
 int ba_solver_set_stream(ba_solver *s, void *hip_stream)
 {
     if (!s) return BA_ERR_ARG;
+    if (s->impl->poisoned) return BA_ERR_HIP;
     if (s->impl->own_stream && s->impl->st) { (void)hipStreamSynchronize(s->impl->st); (void)hipStreamDestroy(s->impl->st); }
     s->impl->st = (hipStream_t)hip_stream;
     s->impl->own_stream = false;
@@ -1137,15 +1242,16 @@ int ba_minimize(ba_solver *s, const ba_lm_params *lm, ba_trial_cb cb, void *user
 {
     return s ? s->impl->minimize(lm, cb, user, out) : BA_ERR_ARG;
 }
-int ba_solver_linearize(ba_solver *s, double *energy, double *diag_max) { return s ? s->impl->linearize(energy, diag_max) : BA_ERR_ARG; }
+#define BA_LIVE(s) ((s) && !(s)->impl->poisoned)
+int ba_solver_linearize(ba_solver *s, double *energy, double *diag_max) { return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->linearize(energy, diag_max); }
 int ba_solver_try_step(ba_solver *s, double lambda, double *energy_test, double *rho_scale, double *dx_norm)
 {
-    return s ? s->impl->try_step(lambda, energy_test, rho_scale, dx_norm) : BA_ERR_ARG;
+    return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->try_step(lambda, energy_test, rho_scale, dx_norm);
 }
-int ba_solver_accept(ba_solver *s) { return s ? s->impl->accept() : BA_ERR_ARG; }
-int ba_solver_stats(ba_solver *s, double *out4) { return (s && out4) ? s->impl->stats(out4) : BA_ERR_ARG; }
-int ba_solver_get(ba_solver *s, int what, double *out, size_t n) { return (s && out) ? s->impl->get(what, out, n) : BA_ERR_ARG; }
-int ba_solver_set_state(ba_solver *s, const double *cam15, const double *pts) { return s ? s->impl->set_state(cam15, pts) : BA_ERR_ARG; }
+int ba_solver_accept(ba_solver *s) { return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->accept(); }
+int ba_solver_stats(ba_solver *s, double *out4) { return !(s && out4) ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->stats(out4); }
+int ba_solver_get(ba_solver *s, int what, double *out, size_t n) { return !(s && out) ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->get(what, out, n); }
+int ba_solver_set_state(ba_solver *s, const double *cam15, const double *pts) { return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->set_state(cam15, pts); }
 
 int ba_solver_timing(ba_solver *s, ba_timing *out, int reset)
 {
@@ -1157,9 +1263,9 @@ int ba_solver_timing(ba_solver *s, ba_timing *out, int reset)
 
 int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, double *ms_per_launch)
 {
-    return s ? s->impl->time_phase(phase, reps, lambda, ms_per_launch) : BA_ERR_ARG;
+    return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->time_phase(phase, reps, lambda, ms_per_launch);
 }
 
-int ba_solver_selftest(ba_solver *s, int which) { return s ? s->impl->selftest(which) : BA_ERR_ARG; }
+int ba_solver_selftest(ba_solver *s, int which) { return !s ? BA_ERR_ARG : !BA_LIVE(s) ? BA_ERR_HIP : s->impl->selftest(which); }
 
 } // extern "C"

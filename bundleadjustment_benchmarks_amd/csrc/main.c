@@ -6,7 +6,8 @@
  * Extensions: the environment variable BA_MAX_TRIALS bounds the number of LM table rows (benchmarking);
  * BA_CACHE=1 keeps a binary cache `<file>.bacache` of the parsed problem and reuses it when present;
  * BA_WORLD / BA_RANK (one process per GPU of a node, started by hand or by a launcher; BA_DEVICE defaults to BA_RANK) shard the
- * points over the processes, which meet through the file BA_COMM_FILE (default /tmp/ba_mi355x_comm.id, written by rank 0) and
+ * points over the processes, which meet through the file BA_COMM_FILE (default /tmp/ba_mi355x_comm.id, written by rank 0 and removed
+ * again once the communicator stands; BA_COMM_NONCE, any string the launcher sets per launch, ties the file to this launch) and
  * then all-reduce the reduced camera system over RCCL inside the library; rank 0 prints.
  */
 #define _POSIX_C_SOURCE 199309L
@@ -98,6 +99,7 @@ int main(int argc, char *argv[])
         const char *idf = getenv("BA_COMM_FILE") ? getenv("BA_COMM_FILE") : "/tmp/ba_mi355x_comm.id";
         rc = ba_comm_id_via_file(idf, rank, id);
         if (rc == BA_OK) rc = ba_solver_comm_init(s, id);
+        (void)ba_comm_id_file_done(idf, rank); /* the communicator stands (or never will): the id must not outlive this launch */
         if (rc != BA_OK) {
             fprintf(stderr, "communicator set-up (rank %d of %d, %s): %s\n", rank, world, idf, ba_error_string(rc));
             ba_solver_free(s);

@@ -137,7 +137,13 @@ typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scal
  * ncclAllReduce calls on the solver's stream, enqueued by ba_minimize without a host synchronisation. */
 #define BA_COMM_ID_BYTES 128
 int ba_comm_unique_id(void *id_out /* BA_COMM_ID_BYTES */);
-int ba_comm_id_via_file(const char *path, int rank, void *id_out); /* rank 0 writes the id (atomic rename), the others wait for it */
+/* Rendezvous through a file for processes started by hand: rank 0 removes whatever an earlier run left at `path`, creates the id and
+ * publishes it (O_EXCL temporary file, mode 0600, atomic rename); the others wait up to 60 s for a file that belongs to THIS launch
+ * (the nonce of the environment variable BA_COMM_NONCE when the launcher sets one, else: not older than two seconds before the
+ * reader's own start).  ba_comm_id_file_done: call after ba_solver_comm_init has returned (it is collective: every rank has the id
+ * by then); rank 0 removes the file, so that no id outlives its launch. */
+int ba_comm_id_via_file(const char *path, int rank, void *id_out);
+int ba_comm_id_file_done(const char *path, int rank);
 
 /* Replaces the construction of BAFunctor + the LM object (bundle_adjustment_large.cpp:117-131): copies the problem
  * to HBM in SoA layout, builds the static camera-pair structure.  Points (and their observations) are partitioned
@@ -210,7 +216,19 @@ int ba_solver_timing(ba_solver *s, ba_timing *out, int reset);
  * 6 dense factorisation only, 7 backward sweep only (6 / 7 rebuild S untimed before every repetition). */
 int ba_solver_time_phase(ba_solver *s, int phase, int reps, double lambda, double *ms_per_launch);
 
-/* Test hook for the failure paths of the in-launch hand-offs (no reference counterpart).  which = 1: runs the one-launch
+/* A hand-off between workgroups of one launch that times out (the fused factorisation's row flag, the one-launch back sweep's
+ * sentinel: waits bounded by design) does not end ba_minimize: the trial is repeated -- and the run continued -- with one launch per
+ * step, where nobody waits for anybody; a second failure returns BA_ERR_HIP.  ba_solver_recoveries counts such repeats.
+ * ba_minimize gives up with BA_ERR_HIP when no LM row appears for BA_WATCHDOG_S seconds (default 600): it does NOT wait for the
+ * stream then, the handle is dead (every later call returns BA_ERR_HIP, ba_solver_free releases no device memory) and a retry
+ * belongs in a fresh process.  BA_ERR_COMM: the shards of a sharded solve took different accept / stop decisions (guard slot of the
+ * scalar all-reduce). */
+int ba_solver_recoveries(const ba_solver *s);
+
+/* Test hook for the failure paths of the in-launch hand-offs (no reference counterpart).  which = 2: arms a fault -- the row
+ * workgroups of the fused factorisation stay silent and the panel's wait is short -- so that the next ba_minimize meets the
+ * time-out on its first trial and has to recover (returns BA_ERR_ARG when the reduced system is a single block column).
+ * which = 3: arms a 4-second kernel in front of the next LM trial (with BA_WATCHDOG_S = 1 ba_minimize must give up).  which = 1: runs the one-launch
  * backward sweep with the workgroup at the head of its dependency chain missing and a short spin bound, so the others
  * wait for unknowns that are never published.  Returns what the production path returns for that: BA_ERR_HIP (the kernels
  * raise a device error word that is read back with the trial's scalars); BA_ERR_ARG when the reduced system has fewer than

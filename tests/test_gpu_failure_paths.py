@@ -17,11 +17,59 @@ def test_backsweep_without_its_producer_returns_err_hip(ba, gpu_ok, capfd):
     assert np.isfinite(et0) and et0 < e
     rc = s.selftest(1)  # the group at the head of the chain never publishes; short spin bound
     assert rc == 5, rc  # BA_ERR_HIP
-    assert "device error 2" in capfd.readouterr().err
+    assert "device error 1024" in capfd.readouterr().err
     # the error word is cleared: the production path works again and reproduces the step
     et1, _, _ = s.try_step(1e-2)
     assert et1 == et0
     assert s.selftest(7) == 4  # unknown self-test: BA_ERR_ARG
+
+
+def test_row_flag_timeout_is_recovered(ba, gpu_ok, capfd):
+    """a hand-off time-out inside the fused factorisation (BA_DEVERR_ROW_FLAG: a row workgroup that was not
+    resident in time) must not end the run.  selftest(2) arms the fault -- the row workgroups stay silent, the panel's wait is
+    short --, ba_minimize meets it on the first trial, repeats that trial through the launch-per-step factorisation (no workgroup
+    waits for another there) and carries on in that mode: same table as a clean solver, one recovery, a notice on stderr."""
+    p = ba.Problem.synthetic(40, 480, 2400, 77)  # D = 360: six block columns, five fused steps
+    ref = ba.Solver(p, ba.CHOLESKY, ba.F64).minimize(max_trials=6)
+    s = ba.Solver(p, ba.CHOLESKY, ba.F64)
+    assert s.selftest(2) == 0
+    r = s.minimize(max_trials=6)
+    err = capfd.readouterr().err
+    assert "device error 1" in err and "repeating LM trial 0" in err
+    assert s.recoveries() == 1
+    assert r["status"] == ref["status"] and r["trials"] == ref["trials"] == 6
+    assert np.array_equal(r["trace"][:, :2], ref["trace"][:, :2])
+    # (the two factorisations round differently and the trajectory amplifies that: 2e-8 in rho by row 1, 8e-6 by row 5)
+    assert np.allclose(r["trace"][:2, 2], ref["trace"][:2, 2], rtol=1e-9) and np.allclose(r["trace"][:, 2:5], ref["trace"][:, 2:5], rtol=1e-4)
+    # the solver stays in the launch-per-step mode: a second run needs no recovery and gives the same table from its new start
+    r2 = s.minimize(max_trials=3)
+    assert s.recoveries() == 1 and r2["trials"] == 3
+    # a reduced system of one block column has no fused step to fail
+    assert ba.Solver(ba.Problem.synthetic(6, 100, 400, 3), ba.QRCHOL, ba.F64).selftest(2) == 4
+
+
+def test_watchdog_returns_instead_of_hanging(ba, gpu_ok, capfd, monkeypatch):
+    """when no LM row appears for BA_WATCHDOG_S seconds ba_minimize must RETURN BA_ERR_HIP -- not fall into a stream
+    synchronise behind the launch it has just declared hung.  selftest(3) puts a 4-second kernel in front of the next trial; with
+    a one-second watchdog the call comes back after about a second, the handle is dead afterwards and frees nothing."""
+    import time
+    monkeypatch.setenv("BA_WATCHDOG_S", "1")
+    p = ba.Problem.synthetic(8, 400, 1500, 3)
+    s = ba.Solver(p, ba.QRCHOL, ba.F64)
+    assert s.selftest(3) == 0
+    t0 = time.time()
+    with pytest.raises(ba.BAError) as ei:
+        s.minimize(max_trials=4)
+    dt = time.time() - t0
+    assert ei.value.code == 5 and 0.9 < dt < 3.5, (ei.value.code, dt)
+    assert "giving up on this solver" in capfd.readouterr().err
+    with pytest.raises(ba.BAError) as ei2:
+        s.linearize()
+    assert ei2.value.code == 5
+    del s  # (ba_solver_free of a dead handle returns at once)
+    time.sleep(3.5)  # let the 4-second kernel end before the next test times anything
+    ok = ba.Solver(p, ba.QRCHOL, ba.F64).minimize(max_trials=2)
+    assert ok["trials"] == 2
 
 
 def test_selftest_refuses_a_single_group(ba, gpu_ok):

@@ -61,6 +61,70 @@ def _worker(rank, world, port, kind, out_q):
         dist.destroy_process_group()
 
 
+def _worker_natural_stop(rank, world, port, out_q):
+    """Two ranks to the reference's own stop (flat-line), one of them with a slow transport."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import bundleadjustment_benchmarks_amd as ba
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        p = ba.Problem.synthetic(24, 3000, 10500, 77)
+        s = ba.Solver(p, ba.CHOLESKY, ba.F64, device=0, shard_rank=rank, shard_world=world)
+        stream = torch.cuda.current_stream()
+        s.set_stream(stream.cuda_stream)
+        calls = [0]
+
+        def allreduce(ptr, count, scalar, op, strm):
+            calls[0] += 1
+            if rank == 1:
+                time.sleep(0.02)  # this rank's host runs behind the other's
+            t = torch.as_tensor(DevArray(ptr, count, scalar), device=dev)
+            stream.synchronize()
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+            t.copy_(c)
+            stream.synchronize()
+            return 0
+        s.set_allreduce(allreduce)
+        r = s.minimize(tol_fun=1e-2)
+        out_q.put((rank, calls[0], r["status"], r["trials"], r["energy"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_natural_stop_same_number_of_collectives(ba, gpu_ok):
+    """VERDICT r2 item 2 / ADVICE r2 (high): at a NATURAL stop (flat-line, not max_trials) every rank must have enqueued the same
+    number of trials -- each carries two all-reduces, and a rank with one more would wait in its collective for ever.  The host
+    enqueues trial n iff row n - LM_DEPTH has arrived with its stop mark clear, so the count is s + LM_DEPTH on every rank whatever
+    its host's timing (one rank's transport is slowed down here).  Tested once."""
+    p = ba.Problem.synthetic(24, 3000, 10500, 77)
+    ref = ba.Solver(p, ba.CHOLESKY, ba.F64).minimize(tol_fun=1e-2)
+    assert ref["status"] == 0 and 3 <= ref["trials"] < 60  # Success by flat-line after a few iterations
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 500
+    procs = [ctx.Process(target=_worker_natural_stop, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted(q.get(timeout=500) for _ in range(2))
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    (_, calls0, st0, tr0, e0), (_, calls1, st1, tr1, e1) = got
+    assert calls0 == calls1, (calls0, calls1)
+    assert st0 == st1 == 0 and tr0 == tr1 and e0 == e1
+    # 3 collectives of the first linearisation (energy, column norms, their maximum) + 2 per enqueued trial; the run ended at row
+    # s = trials - 1, so s + LM_DEPTH (3) trials were enqueued
+    assert calls0 == 3 + 2 * (tr0 - 1 + 3), (calls0, tr0)
+    assert abs(e0 - ref["energy"]) < 3e-2 * ref["energy"]
+
+
 @pytest.mark.parametrize("kind", [2, 1, 3])
 @pytest.mark.timeout(600)
 def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
