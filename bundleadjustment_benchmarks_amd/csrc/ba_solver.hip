@@ -83,6 +83,7 @@ struct SolverBase {
     virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
     virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
     virtual int selftest(int which) = 0;
+    bool unshardable = false; // QRKIT / QRSPQR
     bool poisoned = false; // the watchdog gave up on a launch that never finished: every later call fails, nothing is freed
     int recoveries = 0;    // trials repeated through the launch-per-step factorisation after a hand-off time-out
     ba_allreduce_fn ar_fn = nullptr;
@@ -140,7 +141,9 @@ template <typename T> struct Solver final : SolverBase {
     hipStream_t st_qr = nullptr;   // second stream of the dense QR: trailing updates beside the panel's chunk chain (ba_qr_solve)
     hipEvent_t ev_qr[2] = {nullptr, nullptr};
     int q_rows = 0;
-    bool dense_qr() const { return (kind == BA_QRKIT || kind == BA_QRSPQR) && !sharded(); } // (QRSPQR: see include/ba_mi355x.h)
+    // QRKIT / QRSPQR always run the dense QR of J2bot: a sharded solve on these symbols is REFUSED (ba_solver_create,
+    // ba_solver_comm_init, ba_solver_set_allreduce), never silently turned into QRCHOL's normal equations
+    bool dense_qr() const { return kind == BA_QRKIT || kind == BA_QRSPQR; }
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
     T *h_lam = nullptr; // pinned staging word for lambda
@@ -184,6 +187,7 @@ template <typename T> struct Solver final : SolverBase {
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
     {
         kind = k; rank = rk; world = wd;
+        unshardable = k == BA_QRKIT || k == BA_QRSPQR;
         int rc = ba_build_structure(p, rk, wd, BA_CHUNK, 32 /* lanes of a k_cam_gram group */, &sx);
         if (rc) return rc;
         N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
@@ -322,7 +326,7 @@ template <typename T> struct Solver final : SolverBase {
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
         if ((rc = d_pperm.upload(std::vector<int>(M1, 0 | (1 << 2) | (2 << 4))))) return rc; // identity (CHOLESKY never pivots)
-        if ((kind == BA_QRKIT || kind == BA_QRSPQR) && world == 1) {
+        if (kind == BA_QRKIT || kind == BA_QRSPQR) {
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
             for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
                 for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
@@ -1165,6 +1169,13 @@ int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar,
     if (!p || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return BA_ERR_ARG;
     if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY && kind != BA_MOREQR && kind != BA_QRSPQR) return BA_ERR_ARG;
     if (scalar != BA_F64 && scalar != BA_F32) return BA_ERR_ARG;
+    if ((kind == BA_QRKIT || kind == BA_QRSPQR) && shard_world > 1) {
+        // These symbols exist for the dense QR of J2bot (no normal equations: cond(J2bot) = sqrt(cond(S))).  The exchange step of the
+        // sharded path sums the reduced camera MATRIX, i.e. it would have to square J2bot after all -- QRCHOL under another name.
+        fprintf(stderr, "ba_mi355x: the QRKIT / QRSPQR symbols do not shard (their right block is a dense QR of J2bot, not the all-reduced "
+                        "normal equations): use QRCHOL, CHOLESKY or MOREQR with shard_world > 1\n");
+        return BA_ERR_ARG;
+    }
     *out = nullptr;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
@@ -1197,9 +1208,17 @@ void ba_solver_free(ba_solver *s)
 
 int ba_solver_recoveries(const ba_solver *s) { return s ? s->impl->recoveries : -1; }
 
+static bool ba_kind_does_not_shard(const ba_solver *s, const char *what)
+{
+    if (!s->impl->unshardable) return false;
+    fprintf(stderr, "ba_mi355x: %s refused: the QRKIT / QRSPQR symbols do not shard (dense QR of J2bot, no all-reduced normal equations)\n", what);
+    return true;
+}
+
 int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user)
 {
     if (!s) return BA_ERR_ARG;
+    if (fn && ba_kind_does_not_shard(s, "ba_solver_set_allreduce")) return BA_ERR_ARG;
     s->impl->ar_fn = fn; s->impl->ar_user = user;
     return BA_OK;
 }
@@ -1208,6 +1227,7 @@ int ba_solver_comm_init(ba_solver *s, const void *id)
 {
     if (!s || !id) return BA_ERR_ARG;
     if (s->impl->comm) return BA_ERR_ARG;
+    if (ba_kind_does_not_shard(s, "ba_solver_comm_init")) return BA_ERR_ARG; // (a one-rank communicator too: the path would change)
     return ba_rccl_init(&s->impl->comm, id, s->impl->rank, s->impl->world);
 }
 

@@ -719,6 +719,34 @@ static int FN(solve_reduced_qr)(int N, int M, int K, const int *cam_idx, const i
     return 0;
 }
 
+/* QRSPQR (kind 4): SuiteSparseQR on the WHOLE [J ; sqrt(lambda) I] (typedef SPQR<JacobianType> SchurlikeQRSolver, BAFunctor.h:113-116;
+ * lm.minimize with that solver, bundle_adjustment_large.cpp:151-157; README.md:17 "QR decomposition on full Jacobian").  SuiteSparse
+ * is absent, so what is restated is the definition: a Householder QR of the whole (2K + 3M + 9N) x (3M + 9N) matrix -- all point
+ * AND camera columns, natural order, no block elimination, no fill-reducing ordering (an ordering changes R, not the least-squares
+ * solution) -- and  dx = argmin || [J ; sqrt(lambda) I] dx + [r ; 0] ||  from R dx = -Q^T [r ; 0].  Dense storage: small problems only. */
+static int FN(solve_whole_qr)(int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp, const S *fvec,
+                              S lambda, S *dx)
+{
+    const size_t n = 3 * (size_t)M + 9 * (size_t)N, m = 2 * (size_t)K + n;
+    S *A = (S *)calloc(m * n, sizeof(S));
+    S *b = (S *)calloc(m, sizeof(S));
+    if (!A || !b) { free(A); free(b); return -1; }
+    for (int i = 0; i < K; i++) { /* rows 2i, 2i+1: the 2 x 3 point block and the 2 x 9 camera block of observation i (BAFunctor.h:265-292) */
+        const S *Ac = Jc + 18 * (size_t)i, *Bp = Jp + 6 * (size_t)i;
+        for (int rr = 0; rr < 2; rr++) {
+            for (int c = 0; c < 3; c++) A[(3 * (size_t)pt_idx[i] + c) * m + 2 * (size_t)i + rr] = Bp[3 * rr + c];
+            for (int c = 0; c < 9; c++) A[(3 * (size_t)M + 9 * (size_t)cam_idx[i] + c) * m + 2 * (size_t)i + rr] = Ac[9 * rr + c];
+            b[2 * (size_t)i + rr] = -fvec[2 * (size_t)i + rr];
+        }
+    }
+    const S sl = SQRT(lambda);
+    for (size_t c = 0; c < n; c++) A[c * m + 2 * (size_t)K + c] = sl;
+    FN(dense_qr_solve)((int)m, (int)n, A, b, dx);
+    free(A);
+    free(b);
+    return 0;
+}
+
 /* g = -J^T r (the reference's JtRes, BacktrackLevMarqQRChol.h:267 / ...Cholesky.h:250) and
  * max diag(J^T J) (squared column norms, ...QRChol.h:270-280; JtJ.diagonal().maxCoeff(), ...Cholesky.h:263-265). */
 static void FN(grad_diag)(int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp,
@@ -746,7 +774,7 @@ static void FN(grad_diag)(int N, int M, int K, const int *cam_idx, const int *pt
     if (diagmax) *diagmax = dm;
 }
 
-/* One LM trial's linear solve: dx (3M+9N) from J, r, lambda.  kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY, 3 MOREQR.
+/* One LM trial's linear solve: dx (3M+9N) from J, r, lambda.  kind: 0 QRKIT, 1 QRCHOL, 2 CHOLESKY, 3 MOREQR, 4 QRSPQR.
  * Optional outputs (may be NULL): Sout D*D col-major, rhsout D, gout 3M+9N (= -J^T r, the reference's JtRes,
  * BacktrackLevMarqQRChol.h:267), diagmax = max diag(J^T J) (:270-280). */
 int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const S *Jc, const S *Jp,
@@ -806,6 +834,8 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     S *dxc = dx + 3 * (size_t)M;
     if (assemble_only) {
         /* nothing to solve */
+    } else if (kind == 4) { /* the whole step from the whole-matrix QR (the reduced system above only serves Sout / rhsout) */
+        rc = FN(solve_whole_qr)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, lambda, dx);
     } else if (kind == 0) {
         rc = FN(solve_reduced_qr)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, Q1obs, Q1lam, dxc);
     } else {
@@ -813,7 +843,7 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
         FN(dense_ldlt_solve)(D, Smat, rhs);
         for (int c = 0; c < D; c++) dxc[c] = rhs[c];
     }
-    if (!assemble_only) FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
+    if (!assemble_only && kind != 4) FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
     if (gout || diagmax) FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, gout, diagmax);
     free(Q1obs); free(Q1lam);
     free(e.Z); free(e.dinv); free(e.t); free(e.tri); free(e.perm);

@@ -12,7 +12,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "libba_oracle.so")
 
-QRKIT, QRCHOL, CHOLESKY, MOREQR = 0, 1, 2, 3
+QRKIT, QRCHOL, CHOLESKY, MOREQR, QRSPQR = 0, 1, 2, 3, 4  # (QRSPQR: dense Householder QR of the WHOLE [J; sqrt(lambda) I] -- small problems)
 LM_DEFAULTS = (1e-10, 1e10, 2.0, 1e-8)  # lambda min/max, increaseBase, tolFun (BacktrackLevMarqQRChol.h:131-146)
 
 

@@ -187,3 +187,19 @@ def test_empty_shard_does_not_fault(ba, gpu_ok):
         assert e == 0.0
         et, rs, dn = s.try_step(1.0)
         assert et == 0.0 and np.isfinite(rs) and np.isfinite(dn)
+
+
+def test_qrkit_refuses_a_communicator(ba, gpu_ok, capfd):
+    """The other two ways into the sharded path are refused for QRKIT / QRSPQR as well (and say why): a communicator -- even of one
+    rank: the code path would change -- and a host transport."""
+    p = ba.Problem.synthetic(6, 100, 400, 3)
+    for kind in (ba.QRKIT, ba.QRSPQR):
+        s = ba.Solver(p, kind, ba.F64)
+        with pytest.raises(ba.BAError) as e1:
+            s.comm_init(b"\0" * 128)
+        with pytest.raises(ba.BAError) as e2:
+            s.set_allreduce(lambda *a: 0)
+        assert e1.value.code == 4 and e2.value.code == 4
+        e, _ = s.linearize()  # the solver is unharmed
+        assert np.isfinite(e)
+    assert "do not shard" in capfd.readouterr().err

@@ -263,16 +263,44 @@ def test_qrkit_dense_qr_step_f64(ba, O, gpu_ok, small, prob21, src):
     assert np.array_equal(rg[:, :2], ro[:, :2]) and np.allclose(rg[:3, 2], ro[:3, 2], rtol=1e-7) and np.allclose(rg[:, 2], ro[:, 2], rtol=1e-4)
 
 
-def test_qrspqr_symbol_runs_the_whole_matrix_qr(ba, O, gpu_ok, small):
-    """QRSPQR (SuiteSparseQR on the whole [J ; sqrt(lambda) I]; library absent): the symbol runs the factorisation such a sparse QR
-    performs under a fill-reducing ordering -- per-point QR, then the dense front J2bot -- i.e. the QRKIT path: identical steps."""
-    a = ba.Solver(small, ba.QRSPQR, ba.F64)
-    b = ba.Solver(small, ba.QRKIT, ba.F64)
-    a.linearize(), b.linearize()
-    assert a.try_step(1e-3) == b.try_step(1e-3)
-    assert np.array_equal(a.get(ba.GET_DX), b.get(ba.GET_DX))
-    ra, rb = a.minimize(max_trials=5), b.minimize(max_trials=5)
-    assert np.array_equal(ra["trace"][:, :5], rb["trace"][:, :5])
+@pytest.mark.parametrize("src", ["tiny", "ragged"])
+def test_qrspqr_against_the_whole_matrix_qr(ba, O, gpu_ok, src):
+    """QRSPQR (SuiteSparseQR on the whole [J ; sqrt(lambda) I], BAFunctor.h:113-116; library absent).  The product runs the
+    factorisation a sparse QR performs under a fill-reducing ordering -- the 3-column point blocks first, then the dense front
+    J2bot.  The claim that this IS the whole-matrix QR's step is checked against an oracle that does no block elimination at all:
+    kind 4 = a dense Householder QR of all 3M + 9N columns in natural order (oracle/ba_oracle_impl.h: solve_whole_qr; itself pinned
+    by LAPACK's least-squares solve in tests/test_oracle_math.py).  Step 1e-7, backward error in the normal equations 1e-10, test
+    energy and rho denominator, and the first rows of the LM loop of the symbol.  (Round 2's test compared QRSPQR with QRKIT bit
+    for bit: the alias, not the claim.)"""
+    pg = ba.Problem.synthetic(5, 60, 200, 19) if src == "tiny" else _ragged_problem(ba)
+    po = to_oracle(pg)
+    if src == "ragged":  # the oracle wants observations sorted by point; the product sorts them itself
+        order = np.argsort(po.pt_idx, kind="stable")
+        po = O.Problem(po.N, po.M, po.K, po.cam_idx[order], po.pt_idx[order], po.meas.reshape(-1, 2)[order].ravel(), po.cams9, po.pts)
+    cam = O.init_cams(po)
+    f, e = O.residuals(po, cam, po.pts)
+    Jc, Jp = O.jacobian(po, cam, po.pts)
+    s = ba.Solver(pg, ba.QRSPQR, ba.F64)
+    eg, dmax = s.linearize()
+    assert abs(eg - e) < 1e-12 * e
+    M, N = po.M, po.N
+    for lam in (1e-12 * dmax, 1e-3, 10.0):
+        st = O.step(O.QRSPQR, po, Jc, Jp, f, lam, want_S=False)
+        et, rs, dn = s.try_step(lam)
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
+        Jdx = np.einsum("krc,kc->kr", Jc, dx[3 * M:].reshape(N, 9)[po.cam_idx]) + np.einsum("krc,kc->kr", Jp, dx[:3 * M].reshape(M, 3)[po.pt_idx])
+        res = np.zeros_like(dx)
+        np.add.at(res[3 * M:].reshape(N, 9), po.cam_idx, np.einsum("krc,kr->kc", Jc, Jdx))
+        np.add.at(res[:3 * M].reshape(M, 3), po.pt_idx, np.einsum("krc,kr->kc", Jp, Jdx))
+        assert np.linalg.norm(res + lam * dx - st["g"]) < 1e-10 * np.linalg.norm(st["g"])
+        co, pt = O.retract(po, cam, po.pts, st["dx"])
+        _, e_or = O.residuals(po, co, pt)
+        assert abs(et - e_or) < 1e-7 * e_or
+        assert abs(rs - float(st["dx"] @ (lam * st["dx"] + st["g"]))) < 1e-6 * abs(rs)
+    ro = O.minimize(O.QRSPQR, po, max_trials=6)["trace"]
+    rg = ba.Solver(pg, ba.QRSPQR, ba.F64).minimize(max_trials=6)["trace"]
+    assert np.array_equal(rg[:, :2], ro[:, :2]) and np.allclose(rg[:3, 2], ro[:3, 2], rtol=1e-7) and np.allclose(rg[:, 2], ro[:, 2], rtol=1e-4)
 
 
 def test_f32_lm_decreases(ba, gpu_ok, prob39):

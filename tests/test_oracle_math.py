@@ -96,6 +96,32 @@ def test_step_solves_normal_equations(O, small, kind):
         assert abs(s["diagmax"] - (J.multiply(J)).sum(axis=0).max()) < 1e-12 * s["diagmax"]
 
 
+def test_whole_matrix_qr_symbol(O, ba):
+    """QRSPQR (kind 4): the oracle's Householder QR of the WHOLE [J ; sqrt(lambda) I] (all 3M + 9N columns, natural order, no
+    block elimination) against numpy's LAPACK least-squares solve of the same dense matrix and against the block-eliminating
+    symbols -- an independent route to the same step."""
+    p = to_oracle(ba.Problem.synthetic(5, 60, 200, 19))
+    cam = O.init_cams(p)
+    f, _ = O.residuals(p, cam, p.pts)
+    Jc, Jp = O.jacobian(p, cam, p.pts)
+    J = dense_J(p, Jc, Jp).toarray()
+    n = J.shape[1]
+    for lam in (1e-6, 1e-3, 10.0):
+        s = O.step(O.QRSPQR, p, Jc, Jp, f, lam)
+        A = np.vstack([J, np.sqrt(lam) * np.eye(n)])
+        ref = np.linalg.lstsq(A, -np.concatenate([f, np.zeros(n)]), rcond=None)[0]
+        assert np.linalg.norm(s["dx"] - ref) < 1e-7 * np.linalg.norm(ref)  # (cond of the matrix ~1e6 at lambda = 1e-6)
+        g = -(J.T @ f)
+        assert np.linalg.norm(J.T @ (J @ s["dx"]) + lam * s["dx"] - g) < 1e-10 * np.linalg.norm(g)
+        for kind in (O.QRKIT, O.QRCHOL, O.CHOLESKY):
+            dx = O.step(kind, p, Jc, Jp, f, lam)["dx"]
+            assert np.linalg.norm(dx - s["dx"]) < 1e-7 * np.linalg.norm(s["dx"])
+    # the LM loop runs on the symbol (lambda0 = 1e-12 max diag J'J like QRKIT / QRCHOL)
+    r4 = O.minimize(O.QRSPQR, p, max_trials=6)["trace"]
+    r0 = O.minimize(O.QRKIT, p, max_trials=6)["trace"]
+    assert np.array_equal(r4[:, :2], r0[:, :2]) and np.allclose(r4[:3, 2], r0[:3, 2], rtol=1e-7)
+
+
 def test_three_symbols_agree(O, small):
     p = small
     cam = O.init_cams(p)
