@@ -201,3 +201,22 @@ int ref_jacobian_fd(int N, int M, int K, const int *cam_idx, const int *pt_idx, 
     }
     return 0;
 }
+
+
+/* The whole LM loop (ora_minimize, ba_oracle_impl.h) in quad precision from a double start: the trajectory exact arithmetic would
+ * follow, against which the two fp64 sides' FINAL energies are measured (tests/golden/make_referee.py: free runs).  meas, cam15,
+ * pts, lm as in ora_minimize_f64; cam15 / pts return the final state rounded to double; trace: max_trials x 8 doubles. */
+int ref_minimize(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau, double *cam15,
+                 double *pts, const double *lm, int max_iter, int max_fun_ev, int max_trials, double *trace, int *ntrials_out)
+{
+    S *c = (S *)malloc(sizeof(S) * 15 * (size_t)N), *p = (S *)malloc(sizeof(S) * 3 * (size_t)M), *ms = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    if (!c || !p || !ms) return -4;
+    for (size_t i = 0; i < 15 * (size_t)N; i++) c[i] = cam15[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) p[i] = pts[i];
+    for (size_t i = 0; i < 2 * (size_t)K; i++) ms[i] = meas[i];
+    const int status = ora_minimize_f128(kind, N, M, K, cam_idx, pt_idx, ms, (S)tau, c, p, lm, max_iter, max_fun_ev, max_trials, trace, ntrials_out, NULL);
+    for (size_t i = 0; i < 15 * (size_t)N; i++) cam15[i] = (double)c[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) pts[i] = (double)p[i];
+    free(c); free(p); free(ms);
+    return status;
+}

@@ -37,6 +37,12 @@ CASES = {
     # so only the first rows -- the ones the free-running prefix test of this config looks at
     "cfg4_cholesky": (("synthetic", (257, 65132, 225911, 1004)), O.CHOLESKY, 8),
     "cfg1_cholesky": (("synthetic", (16, 22106, 83718, 1001)), O.CHOLESKY, 24),
+    # config 3 (QRKIT, Scalar = float): the FP32 oracle's own free run to its stop (28 trials, ExceededLambdaMax); the states are
+    # floats, handed to the referee exactly.  The quad trial uses the QRCHOL elimination: the step is the same least-squares
+    # solution whatever the symbol, and in 113 bits the normal equations lose nothing that matters (a quad dense QR of the
+    # 181 633 x 351 J2bot would take ~20 minutes per trial).  The states themselves are kept too (referee_<case>_states.npz,
+    # float32, one per outer iteration): replaying the fp32 oracle's dense QR at test time would take 18 CPU-seconds per trial.
+    "problem39_qrkit_f32": (("bal", "problem-39-18060-pre.txt"), O.QRKIT, 64, np.float32, O.QRCHOL),
 }
 
 
@@ -57,16 +63,23 @@ def _one(args):
     if name not in _P:
         _P[name] = load(CASES[name][0])
     p = _P[name]
-    q = O.referee_trial(kind, p, state[: 15 * p.N], state[15 * p.N:], lam)
+    rkind = CASES[name][4] if len(CASES[name]) > 4 else kind  # (the symbol the quad trial eliminates with)
+    q = O.referee_trial(rkind, p, state[: 15 * p.N], state[15 * p.N:], lam)
     return k, q
 
 
 def make(name, pool):
     source, kind = CASES[name][:2]
     max_trials = CASES[name][2] if len(CASES[name]) > 2 else MAX_TRIALS
+    dtype = CASES[name][3] if len(CASES[name]) > 3 else np.float64
     p = load(source)
-    r = O.minimize(kind, p, max_trials=max_trials, snapshots=True)
+    r = O.minimize(kind, p, dtype=dtype, max_trials=max_trials, snapshots=True)
     tr, sn = r["trace"], r["snap"]
+    if dtype == np.float32:  # the states (exact floats), one per outer iteration, + the map trial -> state
+        it = tr[:, 0].astype(int)
+        first = [int(np.argmax(it == v)) for v in np.unique(it)]
+        np.savez_compressed(os.path.join(HERE, "referee_%s_states.npz" % name), states=sn[first].astype(np.float32),
+                            state_of_trial=np.searchsorted(np.unique(it), it).astype(np.int32))
     jobs = [(name, kind, k, sn[k], float(tr[k][5])) for k in range(len(tr))]
     res = dict(pool.imap_unordered(_one, jobs, chunksize=1))
     rows = []
@@ -78,7 +91,7 @@ def make(name, pool):
                          energy_quad=q["energy"], e_test_quad=q["e_test"], rho_scale_quad=q["rho_scale"],
                          dx_norm_quad=q["dx_norm"], backward_error_quad=q["backward_error"]))
     out = dict(case=name, source=list(source[:1]) + [source[1] if isinstance(source[1], str) else list(source[1])], kind=int(kind),
-               N=p.N, M=p.M, K=p.K, status=int(r["status"]), max_trials=max_trials,
+               N=p.N, M=p.M, K=p.K, status=int(r["status"]), max_trials=max_trials, scalar="f32" if dtype == np.float32 else "f64",
                note="fp64 columns: oracle/ba_oracle.c free run; quad columns: oracle/ba_referee.c from the same (x, lambda) per trial",
                trials=rows)
     with open(os.path.join(HERE, "referee_%s.json" % name), "w") as f:
@@ -88,8 +101,45 @@ def make(name, pool):
           (name, len(rows), r["status"], e[:, 0].max(), e[e[:, 0].argmax(), 1], np.median(e[:, 0])), flush=True)
 
 
+# Free runs in quad precision to the reference's own stop: the trajectory exact arithmetic follows from the same
+# start.  Two fp64 solvers part from it (and from each other) after ~20 trials -- the problem amplifies rounding by ~10x per
+# iteration -- so "final cost to 1e-6" between two fp64 sides is not decidable; what is: whose final energy lies closer to the
+# quad run's.  One run is sequential, ~4 CPU-seconds per trial (10 - 20 minutes).
+FREE_RUNS = {
+    "freerun_problem21_qrchol": (("bal", "problem-21-11315-pre.txt"), O.QRCHOL),
+    "freerun_problem21_cholesky": (("bal", "problem-21-11315-pre.txt"), O.CHOLESKY),
+}
+
+
+def free_run(name):
+    source, kind = FREE_RUNS[name]
+    p = load(source)
+    r = O.referee_minimize(kind, p, max_trials=2000)
+    tr = r["trace"]
+    _, e_final = O.residuals(p, r["cam15"], r["pts"])
+    o = O.minimize(kind, p)  # the fp64 oracle's own free run, for the record
+    out = dict(case=name, source=[source[0], source[1]], kind=int(kind), N=p.N, M=p.M, K=p.K, status=int(r["status"]), trials=int(len(tr)),
+               final_energy_quad=float(O.referee_energy(p, r["cam15"], r["pts"])), final_energy_of_rounded_state_fp64=float(e_final),
+               last_row_energy_quad=float(tr[-1][6] if tr[-1][1] else tr[-1][2]),
+               oracle_fp64=dict(status=int(o["status"]), trials=int(len(o["trace"])),
+                                final_energy=float(O.residuals(p, o["cam15"], o["pts"])[1])),
+               note="quad: oracle/ba_referee.c ref_minimize (ora_minimize in __float128) from the file's start; the energies are of the "
+                    "state the loop leaves behind (the flat-line exit happens before x = xTest, BacktrackLevMarqQRChol.h:419-428)",
+               trace=[[int(w[0]), int(w[1]), float(w[2]), float(w[3]), float(w[4])] for w in tr])
+    with open(os.path.join(HERE, "referee_%s.json" % name), "w") as f:
+        json.dump(out, f, indent=0)
+    print("%s: quad run %d trials, status %d, final energy %.9g; fp64 oracle %d trials, status %d, final energy %.9g" %
+          (name, len(tr), r["status"], out["final_energy_quad"], len(o["trace"]), o["status"], out["oracle_fp64"]["final_energy"]), flush=True)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES)
-    with Pool(int(os.environ.get("REFEREE_PROCS", "8"))) as pool:
-        for n in names:
-            make(n, pool)
+    fr = [n for n in names if n in FREE_RUNS]
+    names = [n for n in names if n not in FREE_RUNS]
+    if names:
+        with Pool(int(os.environ.get("REFEREE_PROCS", "8"))) as pool:
+            for n in names:
+                make(n, pool)
+    if fr:
+        with Pool(len(fr)) as pool:
+            pool.map(free_run, fr)

@@ -217,6 +217,18 @@ def referee_trial(kind, p, cam15, pts, lam, tau=0.5, want_dx=False):
     return r
 
 
+def referee_minimize(kind, p, max_trials=100000, lm=LM_DEFAULTS, max_iter=1000000, max_fun_ev=1000000, tau=0.5):
+    """The LM loop in quad precision from the problem's double start (oracle/ba_referee.c: ref_minimize) -- minutes for problem-21."""
+    cam15 = init_cams(p)
+    pts = p.pts.copy()
+    trace = np.zeros((max_trials, 8))
+    lmv = np.asarray(lm, np.float64)
+    ntr = C.c_int(0)
+    status = referee().ref_minimize(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
+                                    _p(lmv), max_iter, max_fun_ev, max_trials, _p(trace), C.byref(ntr))
+    return dict(status=status, trace=trace[: ntr.value], cam15=cam15, pts=pts)
+
+
 def referee_reduced(kind, p, cam15, pts, lam, tau=0.5):
     """Reduced camera matrix (D x D, symmetric) and rhs of one trial assembled in quad precision, rounded to double."""
     cam15 = np.ascontiguousarray(cam15, np.float64).reshape(-1)

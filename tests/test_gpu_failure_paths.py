@@ -40,7 +40,7 @@ def test_row_flag_timeout_is_recovered(ba, gpu_ok, capfd):
     assert r["status"] == ref["status"] and r["trials"] == ref["trials"] == 6
     assert np.array_equal(r["trace"][:, :2], ref["trace"][:, :2])
     # (the two factorisations round differently and the trajectory amplifies that: 2e-8 in rho by row 1, 8e-6 by row 5)
-    assert np.allclose(r["trace"][:2, 2], ref["trace"][:2, 2], rtol=1e-9) and np.allclose(r["trace"][:, 2:5], ref["trace"][:, 2:5], rtol=1e-4)
+    assert np.allclose(r["trace"][:2, 2], ref["trace"][:2, 2], rtol=1e-7) and np.allclose(r["trace"][:, 2:5], ref["trace"][:, 2:5], rtol=1e-4)
     # the solver stays in the launch-per-step mode: a second run needs no recovery and gives the same table from its new start
     r2 = s.minimize(max_trials=3)
     assert s.recoveries() == 1 and r2["trials"] == 3
