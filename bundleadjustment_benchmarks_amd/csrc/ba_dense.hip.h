@@ -81,20 +81,7 @@ __device__ long long ba_stamp_piv[4 * 4]; // phase s: factor wave has its tile [
 #define BA_STAMP_PIV(j)
 #endif
 
-// LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the
-// compiler must be told that the load below reads what OTHER lanes stored above (it otherwise hoists the load over the
-// lane-predicated store, which is legal for a single thread).
-__device__ __forceinline__ void ba_wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Ordering for the compiler only.  The LDS executes the instructions of ONE wave in order, so a load behind a store of the
-// same wave sees it without any s_waitcnt in between (a wavefront fence would emit one and put the store's round trip in
-// front of the load's: ~45 cycles per pivot in the loops below).
-__device__ __forceinline__ void ba_wave_lds_order() { asm volatile("" ::: "memory"); }
+// (ba_wave_lds_sync / ba_wave_lds_order: ba_mfma.hip.h)
 // Lane K of every row of 16 lanes broadcast to that row (DPP row_newbcast): no LDS round trip.
 template <int K> __device__ __forceinline__ double ba_rowbcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, true); } // ONE v_mov_b64_dpp
 template <int K> __device__ __forceinline__ float ba_rowbcast(float v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, true); }

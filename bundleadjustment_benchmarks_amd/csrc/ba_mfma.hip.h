@@ -27,6 +27,21 @@ __device__ __forceinline__ ba_f4 ba_mfma(float a, float b, ba_f4 c) { return __b
 template <typename T> __device__ __forceinline__ int ba_crow(int lk, int v) { return sizeof(T) == 8 ? lk + 4 * v : 4 * lk + v; }
 
 
+// LDS hand-off between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, but the
+// compiler must be told that the load below reads what OTHER lanes stored above (it otherwise hoists the load over the
+// lane-predicated store, which is legal for a single thread).
+__device__ __forceinline__ void ba_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Ordering for the compiler only.  The LDS executes the instructions of ONE wave in order, so a load behind a store of the
+// same wave sees it without any s_waitcnt in between (a wavefront fence would emit one and put the store's round trip in
+// front of the load's: ~45 cycles per pivot in the loops below).
+__device__ __forceinline__ void ba_wave_lds_order() { asm volatile("" ::: "memory"); }
+
 // ---- wave reduction by DPP (dense back sweep, QRKIT QR) -------------------------------------------------------------
 __device__ __forceinline__ float ba_readlane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
 __device__ __forceinline__ double ba_readlane63(double v)
@@ -36,6 +51,15 @@ __device__ __forceinline__ double ba_readlane63(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
 }
 
+
+// v of lane `k` (wave-uniform k) in every lane
+__device__ __forceinline__ float ba_readlane_dyn(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); }
+__device__ __forceinline__ double ba_readlane_dyn(double v, int k)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), k), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), k);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
 
 // Sum over the 64 lanes, the same value returned to every lane: four butterfly steps inside a row of 16 lanes by DPP (quad
 // permutes, half-row and row mirrors), the two row broadcasts that carry the row sums to lane 63, one v_readlane -- seven vector

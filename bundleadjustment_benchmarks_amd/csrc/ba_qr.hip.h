@@ -11,15 +11,15 @@
 // oracle/ba_oracle_impl.h: solve_reduced_qr).
 //
 // The QR is blocked by 32-column panels; a panel is factored as a TSQR tree so that no reflector ever needs a grid-wide
-// reduction: level 1 cuts the rows into chunks of CH (256 fp32 / 128 fp64) that ONE WAVEFRONT factors in registers (Householder,
+// reduction: level 1 cuts the rows into chunks of CH (1024 fp32 / 512 fp64) that ONE WORKGROUP factors in registers (Householder,
 // column by column, reflectors stored in place below the diagonal of the chunk, the chunk's 32 x 32 R on its top rows); level
 // L + 1 stacks the R's of NSB = CH / 32 level-L chunks (their top rows, in place: row stride CH * NSB^(L-1)) and factors the
 // stack the same way -- its reflectors only have entries where the stacked triangles had them, so they fit in the triangles
-// they annihilate and the lower-level reflectors underneath stay intact.  The trailing columns (and the right-hand side, which
-// rides along as column D) receive the chunk reflectors level by level: one wavefront per (chunk, 32 columns) holds the tile in
-// registers and applies the 32 reflectors one after the other.  No LDS tile and no barrier anywhere: round 2's first version
-// (one workgroup per 1024-row chunk, tile in LDS, five barriers per reflector) spent 8 - 11 us per reflector waiting on LDS
-// round trips and ran 26 ms per trial at config 3.
+// they annihilate and the lower-level reflectors underneath stay intact.  Three levels at config 3 (181 633 rows).
+// Every chunk also leaves the T factor of its 32 reflectors (compact WY: H_0 ... H_31 = I - V T V^T), so the trailing columns
+// (and the right-hand side, which rides along as column D) receive a chunk's reflectors as THREE PRODUCTS ON THE MATRIX CORES
+// -- W = V^T B, Z = T^T W, B -= V Z (k_qr_apply) -- instead of 32 rank-1 updates on the vector units (round 2: 5.8 % of the
+// fp32 rate, 110 launches per trial over five levels).
 #ifndef BA_QR_HIP_H
 #define BA_QR_HIP_H
 
@@ -27,17 +27,20 @@
 #include "ba_mfma.hip.h"
 
 #define BA_QR_PB 32 /* panel width = rows of a sub-block */
-#define BA_QR_CW 8  /* trailing columns per wavefront of k_qr_apply */
 
+// Chunk heights: level 1 -- where the rows are -- takes chunks of NSB = 32 (fp32) / 16 (fp64) sub-blocks of 32 rows (one round of
+// workgroups at config 3: 178 chunks); the upper levels stack NSBU = 16 R's per chunk: a few short tasks whose latency is the
+// panel's critical path (178 -> 12 -> 1 chunks at config 3).
 template <typename T> struct ba_qr_cfg {
-    static constexpr int NSB = sizeof(T) == 4 ? 8 : 4; // sub-blocks (of 32 rows) per chunk
-    static constexpr int CH = BA_QR_PB * NSB;          // rows per chunk = 64 lanes x 4 (fp32) / 2 (fp64) rows: a CH x 32 tile is 128 registers per lane
+    static constexpr int NSB = sizeof(T) == 4 ? 32 : 16; // level 1: sub-blocks per chunk
+    static constexpr int CH = BA_QR_PB * NSB;            // rows per level-1 chunk = 64 lanes x 16 (fp32) / 8 (fp64) rows: a wave's CH x 8 columns are 128 registers per lane
+    static constexpr int NSBU = 16;                      // upper levels (8: one more level at config 3, 137 us of chain per panel against 90)
 };
 
 // global row of local row l of chunk g: sub-block s = l / 32 starts at row0 + (g NSB + s) stride, stride = 32 at level 1
-template <typename T> __device__ __forceinline__ size_t ba_qr_row(int row0, int g, int l, long long stride)
+template <int NSB> __device__ __forceinline__ size_t ba_qr_row(int row0, int g, int l, long long stride)
 {
-    return (size_t)row0 + (size_t)((long long)g * ba_qr_cfg<T>::NSB + (l >> 5)) * (size_t)stride + (size_t)(l & 31);
+    return (size_t)row0 + (size_t)((long long)g * NSB + (l >> 5)) * (size_t)stride + (size_t)(l & 31);
 }
 
 // ---- J2bot ------------------------------------------------------------------------------------------------------------
@@ -98,169 +101,429 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
     }
 }
 
+// Entry l of reflector c of chunk g (local row l of the chunk): 1 on the pivot row, zero above it; below it the stored panel column
+// at level 1, and at the upper levels -- where every sub-block of 32 rows is the R of a lower-level chunk -- only the rows t <= c of
+// the sub-blocks behind the first (the triangle the reflector annihilated; what lies under it is the lower level's reflectors).
+// The load is unconditional from a clamped (valid) address and masked afterwards: a conditional load is compiled as branch + wait.
+// Two steps, so that a batch of loads can be ISSUED before the first of them is looked at: ba_qr_vraw is the plain load,
+// ba_qr_vmask the mask -- with an opaque use of the loaded value in front of it, or the compiler sinks every load under its mask
+// again (a branch and a full wait per load: 44 us per k_qr_apply task instead of 10).
+template <typename T>
+__device__ __forceinline__ T ba_qr_vraw(const T *__restrict__ A, size_t lda, int c0, int bw, size_t grow_l, int c)
+{
+    return A[(size_t)(c0 + (c < bw ? c : 0)) * lda + grow_l];
+}
+template <typename T> __device__ __forceinline__ T ba_qr_vmask(T x, int bw, int level, int rows, int l, int c)
+{
+    asm volatile("" : "+v"(x));
+    const bool stored = c < bw && l > c && l < rows && (level == 1 || ((l >> 5) > 0 && (l & 31) <= c));
+    return stored ? x : ((l == c && c < bw) ? (T)1 : (T)0);
+}
+
+#define BA_QR_TP 36 /* pitch of the per-wave LDS tile [16 rows][32 columns]: fragment reads (lane <-> column, rows 4 q + v) and 16-byte row
+                       writes are both free of bank conflicts (16 q mod 32 separates the two halves of a 32-lane access) */
+// 16 rows x 32 columns between memory and a wave: lane (i, q) owns row i of the EIGHT columns 8 q .. 8 q + 7 -- per instruction
+// (one column per lane) 16 rows of 4 columns = four 64-byte runs; in the LDS tile the lane's eight values are two 16-byte words.
+template <typename T> __device__ __forceinline__ void ba_qr_tile_to_lds(T *st, const T (&x)[8], int i, int q)
+{
+    T *d = st + i * BA_QR_TP + 8 * q;
+#pragma unroll
+    for (int t = 0; t < 8; t++) d[t] = x[t]; // (contiguous, 16-byte aligned: the compiler merges them)
+}
+template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const T *st, T (&x)[8], int i, int q)
+{
+    const T *d = st + i * BA_QR_TP + 8 * q;
+#pragma unroll
+    for (int t = 0; t < 8; t++) x[t] = d[t];
+}
+
 // ---- one chunk of a TSQR level: Householder QR of its rows of the panel, in registers --------------------------------------
 // Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them); the 32 panel columns are dealt to the four wavefronts of
-// the workgroup cyclically.  Step j: the owner of column j forms the reflector (norm below the pivot by a wave reduction, the
-// scalars redundantly in every lane), hands it to the others through LDS and retires the column to memory (R entries above the
-// pivot, beta on it, v below), shifting its registers left by one column so that its next column is at position 0 again -- the
-// loop body is the same for every j; then every wavefront updates its own columns, one wave reduction per column for v . a_c.
+// the workgroup cyclically: wave w owns the columns 4 jq + w, jq = 0 .. 7, at the compile-time register positions jq (the step
+// loop is unrolled over jq: no register is ever moved).  Step j = 4 jq + jw: wave jw forms the reflector of its column jq (norm
+// below the pivot by a wave reduction, the scalars redundantly in every lane), hands it to the others through LDS (double-buffered:
+// one barrier per step) and retires the column to memory (R entries above the pivot, beta on it, v below); then every wave updates
+// its columns behind j, one wave reduction per column for v . a_c.
 // level 1: the chunk's rows are dense; level > 1: every sub-block of 32 rows is an upper triangle (the R of a lower-level chunk) --
 // entries below a sub-block's diagonal are read as zero and never written (the lower level's reflectors live there).
-template <typename T>
+// Tail: the T factor of the chunk's reflectors (compact WY, forward columnwise like LAPACK's larft):
+//   G = V^T V on the matrix cores (each wave its quarter of the rows, summed through LDS), then
+//   T(j, j) = tau_j,  T(0:j, j) = -tau_j T(0:j, 0:j) G(0:j, j)  -- one lane per row of T, 32 dependent steps --
+// written row-major to Tout[chunk][32][32] for k_qr_apply.
+template <typename T, int NSB>
 __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                  T *__restrict__ tau /* [chunks][32] */, int nch)
+                                                  T *__restrict__ Tout /* [chunks][32 * 32] */, int nch)
 {
-    // One workgroup per chunk, wave w owns the panel columns c with (c & 3) == w (eight of them, CW): the column that step j
-    // retires is always at register position 0 of its owner.  The owner forms the reflector (norm, scalars), leaves it in LDS
-    // (double-buffered: one barrier per step) and retires its column; every wave then updates its own columns.
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64, CW = BA_QR_PB / 4;
+    constexpr int CH = BA_QR_PB * NSB, RPL = CH / 64, CW = BA_QR_PB / 4, RTW = CH / 64;
     __shared__ T vs[2][CH];
-    __shared__ T tj_s[2];
+    __shared__ T tj_s[2], taus[BA_QR_PB];
+    __shared__ T Gp[4][BA_QR_PB][BA_QR_PB + 1], Gs[BA_QR_PB][BA_QR_PB + 1]; // partial Gram matrices of the four waves; G, column j at Gs[j][.]
+    __shared__ __attribute__((aligned(16))) T St[4][16 * BA_QR_TP]; // per wave: a 16 x 32 tile of V between the load layout and the operand layout
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = blockIdx.x;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
+    if (threadIdx.x < BA_QR_PB) taus[threadIdx.x] = (T)0;
     T a[RPL][CW];
     size_t grow[RPL];
 #pragma unroll
     for (int e = 0; e < RPL; e++) {
         const int l = lane + 64 * e;
-        grow[e] = ba_qr_row<T>(row0, g, l, stride);
+        grow[e] = ba_qr_row<NSB>(row0, g, l < rows ? l : 0, stride);
 #pragma unroll
         for (int q = 0; q < CW; q++) {
             const int c = 4 * q + wv;
-            a[e][q] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? A[(size_t)(c0 + c) * lda + grow[e]] : (T)0;
+            a[e][q] = A[(size_t)(c0 + (c < bw ? c : 0)) * lda + grow[e]]; // (unconditional; masked below, behind ALL the loads)
         }
     }
-    for (int j = 0; j < bw; j++) {
-        if ((j & 3) == wv) { // (wave-uniform)
-            T part = 0;
 #pragma unroll
-            for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][0] * a[e][0] : (T)0;
-            const T x2 = ba_wave_sum_all<T>(part);
-            const T alpha = __shfl(a[0][0], j, 64); // row j lives in lane j, e = 0 (j < 32)
-            T tj = 0, sc = 0, beta = alpha;
-            if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-                beta = sqrt(alpha * alpha + x2);
-                if (alpha > (T)0) beta = -beta;
-                tj = (beta - alpha) / beta;
-                sc = (T)1.0 / (alpha - beta);
-            }
-            if (lane == 0) { tau[(size_t)g * BA_QR_PB + j] = tj; tj_s[j & 1] = tj; }
-#pragma unroll
-            for (int e = 0; e < RPL; e++) {
-                const int l = lane + 64 * e;
-                const T ve = l > j ? a[e][0] * sc : (l == j ? (T)1 : (T)0);
-                vs[j & 1][l] = ve;
-                const T keep = l > j ? ve : (l == j ? beta : a[e][0]);
-                if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = keep; // retire column j
-#pragma unroll
-                for (int q = 0; q + 1 < CW; q++) a[e][q] = a[e][q + 1];
-                a[e][CW - 1] = 0;
-            }
-        }
-        __syncthreads();
-        const T tj = tj_s[j & 1];
-        T v[RPL];
-#pragma unroll
-        for (int e = 0; e < RPL; e++) v[e] = vs[j & 1][lane + 64 * e];
-        // w_c = tau (v . a_c) for this wave's columns behind j, a_c -= v w_c  (v is 1 on row j, zero above)
+    for (int e = 0; e < RPL; e++) {
+        const int l = lane + 64 * e;
 #pragma unroll
         for (int q = 0; q < CW; q++) {
-            T pd = 0;
+            const int c = 4 * q + wv;
+            T x = a[e][q];
+            asm volatile("" : "+v"(x));
+            a[e][q] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? x : (T)0;
+        }
+    }
+    __syncthreads();
 #pragma unroll
-            for (int e = 0; e < RPL; e++) pd += v[e] * a[e][q];
-            const T w = tj * ba_wave_sum_all<T>(pd);
+    for (int jq = 0; jq < CW; jq++) {
+#pragma unroll 1
+        for (int jw = 0; jw < 4; jw++) {
+            const int j = 4 * jq + jw;
+            if (j >= bw) break; // (uniform; only the last panel is narrower than 32)
+            if (jw == wv) {     // (wave-uniform) this wave's column jq is column j
+                T part = 0;
 #pragma unroll
-            for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * w;
+                for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][jq] * a[e][jq] : (T)0;
+                const T x2 = ba_wave_sum_all<T>(part);
+                const T alpha = __shfl(a[0][jq], j, 64); // row j lives in lane j, e = 0 (j < 32)
+                T tj = 0, sc = 0, beta = alpha;
+                if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
+                    beta = sqrt(alpha * alpha + x2);
+                    if (alpha > (T)0) beta = -beta;
+                    tj = (beta - alpha) / beta;
+                    sc = (T)1.0 / (alpha - beta);
+                }
+                if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
+#pragma unroll
+                for (int e = 0; e < RPL; e++) {
+                    const int l = lane + 64 * e;
+                    const T ve = l > j ? a[e][jq] * sc : (l == j ? (T)1 : (T)0);
+                    vs[j & 1][l] = ve;
+                    const T keep = l > j ? ve : (l == j ? beta : a[e][jq]);
+                    if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = keep; // retire column j
+                }
+            }
+            __syncthreads();
+            const T tj = tj_s[j & 1];
+            T v[RPL];
+#pragma unroll
+            for (int e = 0; e < RPL; e++) v[e] = vs[j & 1][lane + 64 * e];
+            // w_c = tau (v . a_c) for this wave's columns behind j, a_c -= v w_c  (v is 1 on row j, zero above)
+#pragma unroll
+            for (int q = jq; q < CW; q++) {
+                if (q > jq || wv > jw) { // (wave-uniform) column 4 q + wv > j
+                    T pd = 0;
+#pragma unroll
+                    for (int e = 0; e < RPL; e++) pd += v[e] * a[e][q];
+                    const T w = tj * ba_wave_sum_all<T>(pd);
+#pragma unroll
+                    for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * w;
+                }
+            }
+        }
+    }
+    // ---- T factor.  The retired columns are in memory (written by different waves of this workgroup: visible behind the barrier).
+    __syncthreads();
+    {
+        typedef typename ba_acc<T>::type acc_t;
+        const int i = lane & 15, q = lane >> 4;
+        acc_t g00, g01, g11;
+#pragma unroll
+        for (int v = 0; v < 4; v++) { g00[v] = 0; g01[v] = 0; g11[v] = 0; }
+        // V by 64-byte runs of rows (lane (i, q): row i of the columns 4 s + q), into the operand order (lane <-> column, K-step <->
+        // row) through this wave's LDS tile -- like k_qr_apply
+        T *st = St[wv];
+        constexpr int RB = RTW < 4 ? RTW : 4; // row tiles whose loads are in flight together
+#pragma unroll 1
+        for (int rb = 0; rb < RTW; rb += RB) {
+            T vl[RB][8];
+#pragma unroll
+            for (int rt = 0; rt < RB; rt++) {
+                const int l = (wv * RTW + rb + rt) * 16 + i;
+                const size_t gl = ba_qr_row<NSB>(row0, g, l < rows ? l : 0, stride);
+#pragma unroll
+                for (int t = 0; t < 8; t++) vl[rt][t] = ba_qr_vraw<T>(A, lda, c0, bw, gl, 8 * q + t);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RB; rt++) {
+                const int l = (wv * RTW + rb + rt) * 16 + i;
+#pragma unroll
+                for (int t = 0; t < 8; t++) vl[rt][t] = ba_qr_vmask<T>(vl[rt][t], bw, level, rows, l, 8 * q + t);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RB; rt++) {
+                ba_qr_tile_to_lds<T>(st, vl[rt], i, q);
+                ba_wave_lds_order();
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    // G[i][j] += V[l][i] V[l][j]: lane (i, q) holds V[row crow(q, v)][i], which is both the A and the B fragment
+                    const T v0 = st[ba_crow<T>(q, v) * BA_QR_TP + i], v1 = st[ba_crow<T>(q, v) * BA_QR_TP + 16 + i];
+                    g00 = ba_mfma(v0, v0, g00);
+                    g01 = ba_mfma(v0, v1, g01);
+                    g11 = ba_mfma(v1, v1, g11);
+                }
+                ba_wave_lds_order();
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) { // C/D fragment: row = crow(q, v), column = i
+            const int r = ba_crow<T>(q, v);
+            Gp[wv][r][i] = g00[v];
+            Gp[wv][r][16 + i] = g01[v];
+            Gp[wv][16 + r][16 + i] = g11[v];
+            Gp[wv][16 + r][i] = (T)0;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BA_QR_PB * BA_QR_PB; idx += 256) {
+        const int k = idx >> 5, j = idx & 31;
+        Gs[j][k] = (Gp[0][k][j] + Gp[1][k][j]) + (Gp[2][k][j] + Gp[3][k][j]);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        T Trow[BA_QR_PB]; // row `lane` of T (lanes 32 .. 63 idle along)
+#pragma unroll
+        for (int k = 0; k < BA_QR_PB; k++) Trow[k] = (T)0;
+#pragma unroll
+        for (int j = 0; j < BA_QR_PB; j++) {
+            const T tj = taus[j];
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < j; k++) acc += Trow[k] * Gs[j][k]; // (Trow[k] = 0 for k < lane: T is upper triangular)
+            Trow[j] = lane == j ? tj : (lane < j ? -tj * acc : (T)0);
+        }
+        if (lane < BA_QR_PB) {
+            T *to = Tout + (size_t)g * (BA_QR_PB * BA_QR_PB) + (size_t)lane * BA_QR_PB;
+#pragma unroll
+            for (int k = 0; k < BA_QR_PB; k++) to[k] = Trow[k];
         }
     }
 }
 
-// ---- the reflectors of one chunk applied to CW trailing columns: one wavefront per (chunk, column strip), in registers ----------
-// Reflector j of the chunk: 1 at local row j, zero above; below: level 1 -- the stored panel column; level > 1 -- in every
-// sub-block behind the first only the rows t <= j (the triangle it annihilated).  The next reflector's entries are requested
-// while the current one is applied.  Eight columns per wavefront: 32 registers of tile, eight wavefronts per SIMD hide the L2
-// latency of the reflector loads, and a task is 32 x 8 short dependent chains (6 us) -- the upper levels of the tree, where a
-// launch holds a handful of tasks, take as long as one task.
-template <typename T>
-__global__ __launch_bounds__(256) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                  const T *__restrict__ tau, int col0, int col1, int nch, int nct)
+// ---- the reflectors of one chunk applied to 32 trailing columns, on the matrix cores -------------------------------------------------
+// One workgroup of EIGHT waves per (chunk, strip of 32 trailing columns): Q^T B = (I - V T^T V^T) B with the chunk's V (CH x 32) and T
+// (k_qr_chunk), as three products of the 16x16x4 instruction.  The launch is bound by the bytes it moves (~4 TB/s of 64-byte runs),
+// so the strip and the chunk's V are read from memory ONCE: wave w keeps its eighth of the rows in registers from the first load to
+// the last store -- B as C/D fragments (CH / 128 x 2 tiles = 64 registers), V in the order it is loaded in (64 registers):
+//   W = V^T B   the fragment registers of B ARE the B operands (register v of a tile = the rows crow(q, v) of its four K-steps), V is
+//               brought into the same row order; the eight waves' partial sums meet in LDS (fixed order);
+//   Z = T^T W   one 16 x 16 tile on each of four waves;
+//   B -= V Z    eight K-steps per tile: step s takes the reflectors 8 q + s (lane (m, q) holds V[m][8 q + s] from the load; any
+//               one-to-one map of (s, q) onto the 32 reflectors does, as long as Z is read through the same map).
+// Every global access is a 64-byte run of rows per column (lane <-> row; a fragment loaded lane <-> column puts every lane of an
+// instruction into a cache line of its own and the L2 moves sixteen times the tile); the fragments' lane <-> column order is reached
+// through a per-wave LDS tile (ba_qr_tile_*; no barrier: a wave's LDS instructions execute in order).  All loads of a batch are
+// issued before the first is looked at (ba_qr_vraw / ba_qr_vmask).
+// Measured at config 3, first panel's launch (1840 tasks): 180 us = 3.9 TB/s.  A streaming form (nothing held between the passes,
+// five workgroups per CU, next tile prefetched) reads B and V twice and runs at the same ~4.3 TB/s: 250 - 270 us.
+// bw < 32 (last panel): the missing reflectors are zero columns of V and T.  Rows past the matrix (last chunk) and columns past the
+// strip are masked.  Workgroup -> task: the strips of one chunk run next to each other on ONE XCD (blockIdx % 8 under the observed
+// round-robin placement).
+#define BA_QR_AW 8 /* waves of a k_qr_apply workgroup */
+template <typename T, int NSB>
+__global__ __launch_bounds__(64 * BA_QR_AW) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
+                                                           const T *__restrict__ Tg, int col0, int col1, int nch, int nct)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB, CH = ba_qr_cfg<T>::CH, RPL = CH / 64, CW = BA_QR_CW;
-    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= nch * nct) return;
-    const int g = wid % nch, ct = wid / nch; // (neighbouring wavefronts share a column strip and walk neighbouring chunks)
-    const int cb = col0 + CW * ct, ncol = min(CW, col1 - cb);
-    const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
-    T b[RPL][CW];
-    size_t grow[RPL];
+    constexpr int CH = BA_QR_PB * NSB, RTW = CH / (16 * BA_QR_AW), PB = BA_QR_PB;
+    static_assert(RTW >= 1 && PB == 32, "a wave owns at least one row tile; the tile helpers are written for 32 columns");
+    typedef typename ba_acc<T>::type acc_t;
+    __shared__ T Wp[BA_QR_AW][PB][PB + 1], Zs[PB][PB + 1];
+    __shared__ __attribute__((aligned(16))) T St[BA_QR_AW][16 * BA_QR_TP]; // per wave: one 16 x 32 tile between the two layouts, [row][column]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = 8 * (slot / nct) + xcd, ct = slot % nct;
+    if (g >= nch) return; // (uniform)
+    const int cb = col0 + PB * ct, ncol = min(PB, col1 - cb);
+    const int nsb = min(NSB, nsb_total - g * NSB), rows = PB * nsb;
+    T *st = St[wv];
+    // ---- all of V for this wave's rows first (lane (i, q): row i of the reflectors 8 q .. 8 q + 7; kept to the end)
+    T vm[RTW][8];
+    size_t grl[RTW]; // global row of this lane's row of tile rt (clamped)
 #pragma unroll
-    for (int e = 0; e < RPL; e++) {
-        const int l = lane + 64 * e;
-        grow[e] = ba_qr_row<T>(row0, g, l, stride);
+    for (int rt = 0; rt < RTW; rt++) {
+        const int l = (wv * RTW + rt) * 16 + i;
+        grl[rt] = ba_qr_row<NSB>(row0, g, l < rows ? l : 0, stride);
 #pragma unroll
-        for (int c = 0; c < CW; c++) b[e][c] = (c < ncol && l < rows) ? A[(size_t)(cb + c) * lda + grow[e]] : (T)0;
+        for (int t = 0; t < 8; t++) vm[rt][t] = ba_qr_vraw<T>(A, lda, c0, bw, grl[rt], 8 * q + t);
     }
-    auto vload = [&](int j, T (&v)[RPL]) {
+    acc_t Bt[RTW][2], Wt[2][2];
 #pragma unroll
-        for (int e = 0; e < RPL; e++) {
-            const int l = lane + 64 * e;
-            T x = 0;
-            if (l == j) x = 1;
-            else if (l > j && l < rows && (level == 1 ? true : ((l >> 5) > 0 && (l & 31) <= j))) x = A[(size_t)(c0 + j) * lda + grow[e]];
-            v[e] = x;
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Wt[it][jt][v] = 0;
+    // ---- W = V^T B (this wave's rows), the strip on its way into the C/D fragments
+    constexpr int RB = RTW < 4 ? RTW : 4; // row tiles whose loads of B are in flight together
+#pragma unroll
+    for (int rb = 0; rb < RTW; rb += RB) {
+        T bl[RB][8];
+#pragma unroll
+        for (int rt = 0; rt < RB; rt++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int c = 8 * q + t;
+                bl[rt][t] = A[(size_t)(cb + (c < ncol ? c : 0)) * lda + grl[rb + rt]];
+            }
+        if (rb == 0) { // the masks of V behind the first batch of B's loads: everything the wave reads is in flight by now
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++) {
+                const int l = (wv * RTW + rt) * 16 + i;
+#pragma unroll
+                for (int t = 0; t < 8; t++) vm[rt][t] = ba_qr_vmask<T>(vm[rt][t], bw, level, rows, l, 8 * q + t);
+            }
         }
-    };
-    T vn[RPL];
-    vload(0, vn);
-    for (int j = 0; j < bw; j++) {
-        const T tj = tau[(size_t)g * BA_QR_PB + j];
-        T v[RPL];
 #pragma unroll
-        for (int e = 0; e < RPL; e++) v[e] = vn[e];
-        if (j + 1 < bw) vload(j + 1, vn);
+        for (int rt = 0; rt < RB; rt++) {
+            const int l = (wv * RTW + rb + rt) * 16 + i;
 #pragma unroll
-        for (int c = 0; c < CW; c++) {
-            T pd = 0;
+            for (int t = 0; t < 8; t++) {
+                T x = bl[rt][t];
+                asm volatile("" : "+v"(x));
+                bl[rt][t] = (l < rows && 8 * q + t < ncol) ? x : (T)0;
+            }
+            ba_qr_tile_to_lds<T>(st, bl[rt], i, q);
+            ba_wave_lds_order();
 #pragma unroll
-            for (int e = 0; e < RPL; e++) pd += v[e] * b[e][c];
-            const T w = tj * ba_wave_sum_all<T>(pd);
+            for (int jt = 0; jt < 2; jt++)
 #pragma unroll
-            for (int e = 0; e < RPL; e++) b[e][c] -= v[e] * w;
+                for (int v = 0; v < 4; v++) Bt[rb + rt][jt][v] = st[ba_crow<T>(q, v) * BA_QR_TP + 16 * jt + i];
+            ba_wave_lds_order();
+            ba_qr_tile_to_lds<T>(st, vm[rb + rt], i, q);
+            ba_wave_lds_order();
+#pragma unroll
+            for (int v = 0; v < 4; v++) { // (rows past the chunk: V and B are zero there)
+                const T v0 = st[ba_crow<T>(q, v) * BA_QR_TP + i], v1 = st[ba_crow<T>(q, v) * BA_QR_TP + 16 + i];
+                Wt[0][0] = ba_mfma(v0, Bt[rb + rt][0][v], Wt[0][0]);
+                Wt[0][1] = ba_mfma(v0, Bt[rb + rt][1][v], Wt[0][1]);
+                Wt[1][0] = ba_mfma(v1, Bt[rb + rt][0][v], Wt[1][0]);
+                Wt[1][1] = ba_mfma(v1, Bt[rb + rt][1][v], Wt[1][1]);
+            }
+            ba_wave_lds_order();
         }
     }
 #pragma unroll
-    for (int e = 0; e < RPL; e++) {
-        const int l = lane + 64 * e;
+    for (int it = 0; it < 2; it++)
 #pragma unroll
-        for (int c = 0; c < CW; c++)
-            if (c < ncol && l < rows) A[(size_t)(cb + c) * lda + grow[e]] = b[e][c];
+        for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Wp[wv][16 * it + ba_crow<T>(q, v)][16 * jt + i] = Wt[it][jt][v];
+    __syncthreads();
+    // ---- Z = T^T W: waves 0 .. 3 form the tile (w >> 1, w & 1)
+    if (wv < 4) {
+        const int it = wv >> 1, jt = wv & 1;
+        const T *Tc = Tg + (size_t)g * (PB * PB);
+        acc_t z;
+#pragma unroll
+        for (int v = 0; v < 4; v++) z[v] = 0;
+#pragma unroll
+        for (int s = 0; s < PB / 4; s++) {
+            const int k = 4 * s + q;
+            const T ta = Tc[(size_t)k * PB + 16 * it + i]; // A[i][k] = T[k][i]
+            T wb = 0;
+#pragma unroll
+            for (int w = 0; w < BA_QR_AW; w++) wb += Wp[w][k][16 * jt + i];
+            z = ba_mfma(ta, wb, z);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) Zs[16 * it + ba_crow<T>(q, v)][16 * jt + i] = z[v];
+    }
+    __syncthreads();
+    // ---- B -= V Z, and back to memory the way it came
+    T zb[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) zb[s][jt] = Zs[8 * q + s][16 * jt + i]; // B[k][n] = Z[8 q + s][n]
+#pragma unroll
+    for (int rt = 0; rt < RTW; rt++) {
+        const int lt = (wv * RTW + rt) * 16, l = lt + i;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            Bt[rt][0] = ba_mfma(-vm[rt][s], zb[s][0], Bt[rt][0]);
+            Bt[rt][1] = ba_mfma(-vm[rt][s], zb[s][1], Bt[rt][1]);
+        }
+        if (lt < rows) { // (wave-uniform)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) st[ba_crow<T>(q, v) * BA_QR_TP + 16 * jt + i] = Bt[rt][jt][v];
+            ba_wave_lds_order();
+            T o[8];
+            ba_qr_tile_from_lds<T>(st, o, i, q);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int c = 8 * q + t;
+                if (l < rows && c < ncol) A[(size_t)(cb + c) * lda + grl[rt]] = o[t];
+            }
+            ba_wave_lds_order();
+        }
     }
 }
 
 // ---- R y = (Q^T rhs)[0 : D): back substitution by one workgroup ------------------------------------------------------------
-// R is the upper triangle of the first D rows of A, the transformed right-hand side column D.  Column-oriented: y_j =
-// b_j / R_jj, then b_i -= R_ij y_j for i < j (the column of R is contiguous in memory).
+// R is the upper triangle of the first D rows of A, the transformed right-hand side column D.  Blocks of 64 unknowns from the bottom:
+// wave 0 solves the 64 x 64 triangle (lane i = row i, the unknowns handed down by readlane: no barrier inside a block), then all
+// 256 threads eliminate the block from the rows above it (thread = row, the block's columns of R walked down their contiguous
+// direction).  Six blocks at D = 351 instead of 351 steps with two barriers each (0.24 ms -> ~0.03 ms).
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, size_t lda, int D, T *__restrict__ y)
 {
     extern __shared__ unsigned char smem_raw[];
-    T *b = reinterpret_cast<T *>(smem_raw);
+    T *b = reinterpret_cast<T *>(smem_raw); // D right-hand sides, 64 unknowns of the current block, its 64 x 64 triangle [k][i]
+    T *yb = b + D, *tri = yb + 64;
     const int tid = threadIdx.x;
     for (int i = tid; i < D; i += 256) b[i] = A[(size_t)D * lda + i];
-    __syncthreads();
-    for (int j = D - 1; j >= 0; j--) {
-        const T *col = A + (size_t)j * lda;
-        const T yj = b[j] / col[j];
+    for (int j1 = D; j1 > 0; j1 -= 64) {
+        const int j0 = j1 > 64 ? j1 - 64 : 0, nb = j1 - j0;
+        for (int idx = tid; idx < 64 * 64; idx += 256) { // the block's triangle, by runs of rows (a load inside the solve loop would put an
+            const int k = idx >> 6, i = idx & 63;        // L2 round trip into every one of its 64 dependent steps)
+            tri[idx] = (k < nb && i <= k) ? A[(size_t)(j0 + k) * lda + j0 + i] : (T)0;
+        }
         __syncthreads();
-        if (tid == 0) { b[j] = yj; y[j] = yj; }
-        for (int i = tid; i < j; i += 256) b[i] -= col[i] * yj;
+        if (tid < 64) { // wave 0: rows j0 .. j1 - 1, lane i holds b[j0 + i]
+            const int i = tid;
+            T bi = i < nb ? b[j0 + i] : (T)0;
+            const T dii = i < nb ? tri[64 * i + i] : (T)1;
+            for (int k = nb - 1; k >= 0; k--) {
+                const T yk = ba_readlane_dyn(bi, k) / ba_readlane_dyn(dii, k);
+                bi -= (i < k ? tri[64 * k + i] : (T)0) * yk;
+                if (i == k) { yb[k] = yk; y[j0 + k] = yk; }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += 256) { // rows above the block (eight loads in flight: one per trip of the loop paid the L2 latency 64 times)
+            T acc = b[i];
+            int k = 0;
+            for (; k + 8 <= nb; k += 8) {
+                T r8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) r8[u] = A[(size_t)(j0 + k + u) * lda + i];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc -= r8[u] * yb[k + u];
+            }
+            for (; k < nb; k++) acc -= A[(size_t)(j0 + k) * lda + i] * yb[k];
+            b[i] = acc;
+        }
         __syncthreads();
     }
 }
 
 // Host side: QR of the (mrows x D) matrix A (+ rhs in column D) on `st`, then y = argmin || A y - rhs ||.
-// A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: room for (ceil(mrows / CH) + 2) * 32 scalars per level, 8 levels
-// (CH = 256 / 128 rows: 181 633 rows are 5 levels in fp32, 7 in fp64).
+// A: lda >= mrows + 64 rows allocated and zero beyond mrows.  tau: the T factors, room for (ceil(mrows / CH) + 2) * 32 * 32 scalars per
+// level, 8 levels (CH = 1024 / 512 rows: 181 633 rows are 3 levels in fp32, 4 in fp64).
 // st2 != nullptr (with two events): the trailing updates run on st2 beside the panel's chunk chain -- level L + 1 of the chain only
 // needs the panel's own R's from level L, not the trailing update of level L -- and the next panel waits for the last of them
 // (fork / join by events: also valid inside a stream capture).  6.2 -> 5.3 ms per trial at config 3.  With look-ahead on top (every
@@ -270,18 +533,20 @@ template <typename T>
 inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, hipStream_t st2 = nullptr,
                         hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
 {
-    constexpr int NSB = ba_qr_cfg<T>::NSB;
+    constexpr int NSB1 = ba_qr_cfg<T>::NSB, NSBU = ba_qr_cfg<T>::NSBU;
     const bool two = st2 != nullptr && ev_chunk != nullptr && ev_apply != nullptr;
     for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
         const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
         const int col0 = c0 + bw, col1 = D + 1; // trailing columns incl. the right-hand side
         int nsb = (mrows - c0 + BA_QR_PB - 1) / BA_QR_PB; // 32-row blocks from the panel's first row down
         long long stride = BA_QR_PB;
-        const int nct = (col1 - col0 + BA_QR_CW - 1) / BA_QR_CW;
+        const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB; // strips of 32 trailing columns
         for (int level = 1;; level++) {
-            const int nch = (nsb + NSB - 1) / NSB;
+            const int fan = level == 1 ? NSB1 : NSBU;
+            const int nch = (nsb + fan - 1) / fan;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
-            hipLaunchKernelGGL((k_qr_chunk<T>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
             if (nct > 0) {
                 hipStream_t sa = st;
                 if (two) {
@@ -289,19 +554,23 @@ inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *t
                     (void)hipStreamWaitEvent(st2, ev_chunk, 0);
                     sa = st2;
                 }
-                hipLaunchKernelGGL((k_qr_apply<T>), dim3((unsigned)(((long long)nch * nct + 3) / 4)), dim3(256), 0, sa, A, lda, c0, bw, c0, level, stride, nsb,
-                                   (const T *)tl, col0, col1, nch, nct);
+                // (8 x ceil(nch / 8) x nct workgroups: chunk g's strips sit at blockIdx % 8 == g % 8)
+                const dim3 ga((unsigned)(8ll * ((nch + 7) / 8) * nct));
+                if (level == 1)
+                    hipLaunchKernelGGL((k_qr_apply<T, NSB1>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1, nch, nct);
+                else
+                    hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1, nch, nct);
             }
             if (nch == 1) break;
             nsb = nch;
-            stride *= NSB;
+            stride *= fan;
         }
         if (two && nct > 0) { // the next panel (and the back substitution) read what the trailing updates wrote
             (void)hipEventRecord(ev_apply, st2);
             (void)hipStreamWaitEvent(st, ev_apply, 0);
         }
     }
-    hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)D, st, (const T *)A, lda, D, y);
+    hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)(D + 64 + 64 * 64), st, (const T *)A, lda, D, y);
 }
 
 #endif

@@ -338,7 +338,7 @@ template <typename T> struct Solver final : SolverBase {
                 for (auto &e : ev_qr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             q_lda = (size_t)q_rows + 64;
-            q_tau_stride = (size_t)((q_rows + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB;
+            q_tau_stride = (size_t)((q_rows + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB * BA_QR_PB; // a 32 x 32 T factor per chunk
             AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, 8 * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
         }
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
