@@ -38,11 +38,11 @@ CASES = {
     "cfg4_cholesky": (("synthetic", (257, 65132, 225911, 1004)), O.CHOLESKY, 8),
     "cfg1_cholesky": (("synthetic", (16, 22106, 83718, 1001)), O.CHOLESKY, 24),
     # config 3 (QRKIT, Scalar = float): the FP32 oracle's own free run to its stop (28 trials, ExceededLambdaMax); the states are
-    # floats, handed to the referee exactly.  The quad trial uses the QRCHOL elimination: the step is the same least-squares
+    # floats, handed to the referee exactly (the first 24 trials: 17 states, 3.7 MB).  The quad trial uses the QRCHOL elimination: the step is the same least-squares
     # solution whatever the symbol, and in 113 bits the normal equations lose nothing that matters (a quad dense QR of the
     # 181 633 x 351 J2bot would take ~20 minutes per trial).  The states themselves are kept too (referee_<case>_states.npz,
     # float32, one per outer iteration): replaying the fp32 oracle's dense QR at test time would take 18 CPU-seconds per trial.
-    "problem39_qrkit_f32": (("bal", "problem-39-18060-pre.txt"), O.QRKIT, 64, np.float32, O.QRCHOL),
+    "problem39_qrkit_f32": (("bal", "problem-39-18060-pre.txt"), O.QRKIT, 24, np.float32, O.QRCHOL),
 }
 
 
@@ -132,8 +132,50 @@ def free_run(name):
           (name, len(tr), r["status"], out["final_energy_quad"], len(o["trace"]), o["status"], out["oracle_fp64"]["final_energy"]), flush=True)
 
 
+# What "the final cost" of this algorithm is worth as a number: the fp64 oracle's own free run from inputs perturbed by 1e-13
+# (relative, seeded) -- far below anything the BAL files' 17 printed digits mean.  The run amplifies that by ~10x per iteration, so
+# the runs part after ~15 iterations and stop (same flat-line test) at different energies: the spread of the ensemble is the
+# resolution at which ANY implementation's final energy can be compared with the reference's.
+ENSEMBLES = {
+    "ensemble_problem21_qrchol": (("bal", "problem-21-11315-pre.txt"), O.QRCHOL, 16),
+    "ensemble_problem21_cholesky": (("bal", "problem-21-11315-pre.txt"), O.CHOLESKY, 16),
+}
+
+
+def _member(args):
+    name, k = args
+    source, kind, _ = ENSEMBLES[name]
+    p = load(source)
+    rng = np.random.default_rng(1000 + k)
+    if k > 0:  # member 0 is the unperturbed input
+        p = O.Problem(p.N, p.M, p.K, p.cam_idx, p.pt_idx, p.meas, p.cams9 * (1 + 1e-13 * rng.standard_normal(p.cams9.shape)),
+                      p.pts * (1 + 1e-13 * rng.standard_normal(p.pts.shape)))
+    r = O.minimize(kind, p)
+    return k, int(r["status"]), int(len(r["trace"])), float(O.residuals(p, r["cam15"], r["pts"])[1])
+
+
+def ensemble(name, pool):
+    source, kind, n = ENSEMBLES[name]
+    res = sorted(pool.map(_member, [(name, k) for k in range(n)]))
+    e = np.array([w[3] for w in res])
+    out = dict(case=name, source=[source[0], source[1]], kind=int(kind), perturbation=1e-13,
+               members=[dict(member=w[0], status=w[1], trials=w[2], final_energy=w[3]) for w in res],
+               final_energy_min=float(e.min()), final_energy_max=float(e.max()), final_energy_median=float(np.median(e)),
+               note="fp64 oracle free runs (oracle/ba_oracle.c) to the reference's own stop from inputs perturbed by 1e-13 relative; member 0 unperturbed")
+    with open(os.path.join(HERE, "referee_%s.json" % name), "w") as f:
+        json.dump(out, f, indent=0)
+    print("%s: final energies %.6g .. %.6g (median %.6g), trials %d .. %d" % (name, e.min(), e.max(), np.median(e), min(w[2] for w in res), max(w[2] for w in res)),
+          flush=True)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES)
+    en = [n for n in names if n in ENSEMBLES]
+    names = [n for n in names if n not in ENSEMBLES]
+    if en:
+        with Pool(int(os.environ.get("REFEREE_PROCS", "8"))) as pool:
+            for n in en:
+                ensemble(n, pool)
     fr = [n for n in names if n in FREE_RUNS]
     names = [n for n in names if n not in FREE_RUNS]
     if names:

@@ -97,3 +97,100 @@ def test_gpu_is_as_close_to_quad_as_the_oracle(ba, O, gpu_ok, name):
     decisive = m[:, 8] > 10 * np.maximum(err_o, err_g) + 1e-12
     acc_g = m[:, 5] < m[:, 1]
     assert np.array_equal(acc_g[decisive], m[decisive, 7] > 0.5)
+
+
+# ---- fp32 (config 3: QRKIT, Scalar = float) --------------------------------------------------------------------------------------------
+# round 2 asserted config 3 at trial 0 only.  tests/golden/referee_problem39_qrkit_f32.json holds the first 24 trials
+# of the FP32 oracle's own free run on problem-39 under QRKIT (dense Householder QR of J2bot in float), each evaluated in quad from the
+# same (float) state; ..._states.npz holds the states.  The GPU (BA_QRKIT, BA_F32: k_elim_qr + the dense QR of ba_qr.hip.h) gets the same
+# state and lambda per trial.  Same assertions as the fp64 cases, with the floor of a float evaluation (1e-6) in place of 1e-13.
+# Then the GPU's OWN trajectory: a Levenberg-Marquardt run driven through the step-level seam (GPU steps, the reference's accept / lambda
+# rule), and at every third of its first 24 states the quad value and the fp32 oracle's step from that very state.
+
+def _fp32_sides(args):
+    """(state, lambda) -> (fp32 oracle's test energy, quad test energy): CPU, 18 + 8 seconds."""
+    import oracle_lib as OL
+    x, lam = args
+    p = OL.load_bal(DATA39)
+    N = p.N
+    cam = x[: 15 * N].astype(np.float32)
+    pts = x[15 * N:].astype(np.float32)
+    f, _ = OL.residuals(p, cam, pts)
+    Jc, Jp = OL.jacobian(p, cam, pts)
+    st = OL.step(OL.QRKIT, p, Jc, Jp, f, np.float32(lam), want_S=False)
+    co, pt = OL.retract(p, cam, pts, st["dx"])
+    _, eo = OL.residuals(p, co, pt)
+    q = OL.referee_trial(OL.QRCHOL, p, x[: 15 * N], x[15 * N:], float(lam))
+    return float(eo), float(q["e_test"]), float(q["energy"])
+
+
+def _regime_asserts(name, lam, err_o, err_g, floor):
+    ll = np.log10(lam)
+    for k in range(len(lam)):
+        cap = 4 * err_o[np.abs(ll - ll[k]) <= 1.0].max()
+        assert err_g[k] <= max(4 * err_o[k], cap) + floor, (name, k, lam[k], err_g[k], err_o[k], cap)
+    ratio = np.maximum(err_g, floor) / np.maximum(err_o, floor)
+    gm = float(np.exp(np.mean(np.log(ratio))))
+    print("   %s: %d trials, geometric mean of (GPU error / fp32-oracle error) %.2f; GPU closer to quad in %d; medians oracle %.2e gpu %.2e" %
+          (name, len(lam), gm, int((err_g < err_o).sum()), np.median(err_o), np.median(err_g)))
+    assert gm <= 2.0, (name, gm)
+    assert np.median(err_g) <= 3 * np.median(err_o) + floor, (name, np.median(err_g), np.median(err_o))
+
+
+@pytest.mark.timeout(900)
+def test_fp32_qrkit_is_as_close_to_quad_as_the_fp32_oracle(ba, O, gpu_ok):
+    with open(os.path.join(GOLD, "referee_problem39_qrkit_f32.json")) as f:
+        fx = json.load(f)
+    z = np.load(os.path.join(GOLD, "referee_problem39_qrkit_f32_states.npz"))
+    pg = ba.Problem.load_bal(DATA39)
+    N = pg.N
+    s = ba.Solver(pg, ba.QRKIT, ba.F32)
+    tr = fx["trials"]
+    rows = []
+    for k, w in enumerate(tr):
+        x = z["states"][z["state_of_trial"][k]].astype(np.float64)
+        s.set_state(x[: 15 * N].reshape(N, 15), x[15 * N:])
+        e, _ = s.linearize(False)
+        et, _, _ = s.try_step(w["lam"])
+        eq = w["e_test_quad"]
+        rows.append((w["lam"], abs(w["e_test_fp64"] - eq) / eq, abs(et - eq) / eq, abs(e - w["energy_quad"]) / w["energy_quad"], et, w["energy_fp64"], eq, w["energy_quad"]))
+    m = np.array(rows)
+    assert np.all(np.isfinite(m[:, 4]))
+    assert m[:, 3].max() < 5e-6  # energy at x_k in float: evaluation only
+    print("\nproblem39 QRKIT fp32, the fp32 oracle's trajectory:")
+    _regime_asserts("injected", m[:, 0], m[:, 1], m[:, 2], 1e-6)
+    # accept / reject against the truth wherever the truth is decisive for both float sides
+    margin = np.abs(m[:, 6] - m[:, 7]) / m[:, 7]
+    decisive = margin > 10 * np.maximum(m[:, 1], m[:, 2]) + 1e-5
+    assert np.array_equal((m[:, 4] < m[:, 5])[decisive], (m[:, 6] < m[:, 7])[decisive])
+
+    # ---- the GPU's own trajectory
+    x0 = z["states"][0].astype(np.float64)
+    s.set_state(x0[: 15 * N].reshape(N, 15), x0[15 * N:])
+    e, dmax = s.linearize()
+    lam, inc = float(np.float32(1e-12 * dmax)), 2.0
+    own = []
+    for k in range(24):
+        x = np.concatenate([s.get(ba.GET_CAMS), s.get(ba.GET_POINTS)])
+        et, rs, _ = s.try_step(lam)
+        own.append((x, lam, et))
+        if et < e:  # BacktrackLevMarqQRChol.h:374-394
+            rho = (e - et) / rs
+            lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e-10)
+            inc = 2.0
+            s.accept()
+            e, _ = s.linearize(False)
+        else:       # :395-410
+            lam *= inc
+            inc = inc ** 1.5
+        lam = float(np.float32(lam))
+    pick = own[::3]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(8, len(pick))) as pool:
+        sides = pool.map(_fp32_sides, [(x, lam) for x, lam, _ in pick])
+    lam = np.array([w[1] for w in pick])
+    eg = np.array([w[2] for w in pick])
+    eo = np.array([w[0] for w in sides])
+    eq = np.array([w[1] for w in sides])
+    print("problem39 QRKIT fp32, the GPU's own trajectory (every third of its first 24 states):")
+    _regime_asserts("own", lam, np.abs(eo - eq) / eq, np.abs(eg - eq) / eq, 1e-6)
