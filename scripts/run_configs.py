@@ -30,8 +30,10 @@ for name in cfgs:
            "gpu_trials_per_s": r["trials"] / el, "gpu_schur_ms": r["schur_ms"], "gpu_final_energy": r["energy"],
            "initial_energy": float(r["trace"][0, 2]), "mean_err_before": st0["mean_err"], "mean_err_after": st1["mean_err"],
            "inliers_before": st0["n_inliers"], "inliers_after": st1["n_inliers"]}
-    if name in ("cfg2", "cfg3", "cfg1"):
+    if name in ("cfg2", "cfg3", "cfg1", "cfg4"):
         po = to_oracle(prob)
+        if name == "cfg4":
+            O.set_threads(os.cpu_count() or 1)  # (328 trials at D = 2313: minutes on one core; the results do not depend on the thread count)
         okind = {"QRKIT": O.QRCHOL, "QRCHOL": O.QRCHOL, "CHOLESKY": O.CHOLESKY}[kind_s]
         t0 = time.perf_counter()
         ro = O.minimize(okind, po, dtype=np.float64 if scalar_s == "f64" else np.float32, max_trials=cap)
@@ -70,5 +72,18 @@ for name in cfgs:
         row.update({"cpu_status": ba.STATUS[ro["status"]], "cpu_trials": len(tr), "cpu_seconds": elo, "cpu_trials_per_s": len(tr) / elo,
                     "cpu_final_energy": float(e_fin), "rel_final_energy_diff": abs(float(e_fin) - r["energy"]) / float(e_fin),
                     "first_accept_reject_difference_at_trial": int(same[0]) + 1 if len(same) else None})
+    # what "the final cost" resolves to on this input: the fp64 oracle's own free runs from inputs perturbed by 1e-13, and the free run
+    # in quad precision (tests/golden/make_referee.py; problem-21 only)
+    gold = os.path.join(ROOT, "tests", "golden")
+    tag = {"cfg2": "problem21_qrchol"}.get(name)
+    if tag:
+        ens = json.load(open(os.path.join(gold, "referee_ensemble_%s.json" % tag)))
+        fr = json.load(open(os.path.join(gold, "referee_freerun_%s.json" % tag)))
+        row.update({"oracle_ensemble_1e-13_final_energy_min": ens["final_energy_min"], "oracle_ensemble_1e-13_final_energy_max": ens["final_energy_max"],
+                    "oracle_ensemble_1e-13_final_energy_median": ens["final_energy_median"], "quad_free_run_final_energy": fr["final_energy_quad"],
+                    "quad_free_run_trials": fr["trials"],
+                    "abs_diff_gpu_vs_quad_final": abs(r["energy"] - fr["final_energy_quad"]),
+                    "abs_diff_cpu_vs_quad_final": abs(row["cpu_final_energy"] - fr["final_energy_quad"]),
+                    "gpu_final_inside_ensemble_range": bool(ens["final_energy_min"] <= r["energy"] <= ens["final_energy_max"])})
     rows.append(row)
     print(json.dumps(row), flush=True)
