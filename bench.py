@@ -179,7 +179,7 @@ def main():
         D = 9 * N
         b_evalRJ, b_evalR, b_schur = algorithmic_bytes(N, M, K, S)
         ntr = max(tm["n_trials"], 1)
-        label = kind_s + (" solver (per-point QR + dense Householder QR of J2bot; the symbol does not shard)" if kind_s == "QRKIT" else " solver")
+        label = kind_s + (" solver (per-point QR + dense Householder QR of J2bot; sharded: distributed TSQR, the shards' R factors are all-reduced)" if kind_s == "QRKIT" else " solver")
         out = {
             "metric": "LM iterations/sec", "value": steps_done / el, "unit": "LM iterations/s", "n_gpus": world,
             "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps_done, 1),

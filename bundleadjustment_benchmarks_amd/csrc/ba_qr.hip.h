@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
                                                      const T *__restrict__ r /* SoA [2][K] */, const T *__restrict__ rec,
                                                      const T *__restrict__ q1obs /* [K][6] */, const T *__restrict__ q1lam /* [Ml][9] */,
                                                      const T *__restrict__ tvec /* SoA [3][Ml] = -q1 */, const T *__restrict__ lam,
-                                                     T *__restrict__ A, size_t lda)
+                                                     T *__restrict__ A, size_t lda, int cam_rows /* sharded: the camera rows belong to shard 0 */)
 {
     const int ia = blockIdx.x * 256 + threadIdx.x;
-    if (ia < D) A[(size_t)ia * lda + 2 * (size_t)K + 3 * (size_t)Ml + ia] = sqrt(*lam); // camera rows: sqrt(lambda) I_D, zero rhs
+    if (cam_rows && ia < D) A[(size_t)ia * lda + 2 * (size_t)K + 3 * (size_t)Ml + ia] = sqrt(*lam); // camera rows: sqrt(lambda) I_D, zero rhs
     if (ia >= K) return;
     const int j = obs_pt[ia], a = obs_cam[ia], b = pt_ptr[j], e = pt_ptr[j + 1];
     const size_t r0 = 2 * (size_t)b + 3 * (size_t)j;
@@ -529,9 +529,41 @@ __global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, s
 // (fork / join by events: also valid inside a stream capture).  6.2 -> 5.3 ms per trial at config 3.  With look-ahead on top (every
 // level's reflectors to the next panel's 32 columns first, on `st`, so that the next chain starts before the rest is done) it was
 // 5.7 ms: five more launches of one task's latency each on the critical stream cost more than the overlap gives.
+// ---- sharded QRKIT: distributed TSQR ----------------------------------------------------------------------------------------------
+// Every shard factors the rows of J2bot it owns (ba_qr_factor); what it contributes to the whole matrix's factor is its D x D
+// triangle R_r and the head of Q_r^T rhs.  k_qr_stack_pack copies both into block r of a zeroed (world D) x (D + 1) matrix, behind
+// it this shard's camera gradient g_c (D) and its part of the energy (1): ONE sum all-reduce of that buffer gives every shard the
+// stack [R_0; R_1; ...] (+ rhs), the global g_c and the energy; the QR of the stack (same kernels, ~world D rows) and the back
+// substitution then run redundantly.  No normal equations anywhere: cond stays that of J2bot.
 template <typename T>
-inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, hipStream_t st2 = nullptr,
-                        hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
+__global__ __launch_bounds__(256) void k_qr_stack_pack(const T *__restrict__ A, size_t lda, int D, int rank, T *__restrict__ B, size_t ldb, size_t nmat,
+                                                       const T *__restrict__ gc, const T *__restrict__ scal, int eloc)
+{
+    const int c = blockIdx.x; // column 0 .. D (D = the right-hand side)
+    if (c > D) { // the tail: g_c, energy
+        for (int i = threadIdx.x; i < D; i += 256) B[nmat + i] = gc[i];
+        if (threadIdx.x == 0) B[nmat + D] = scal[eloc];
+        return;
+    }
+    const int top = c < D ? c : D - 1; // rows 0 .. top of the column belong to R (the reflectors sit below)
+    for (int i = threadIdx.x; i <= top; i += 256) B[(size_t)c * ldb + (size_t)rank * D + i] = A[(size_t)c * lda + i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_stack_unpack(const T *__restrict__ B, size_t nmat, int D, T *__restrict__ gc_out, T *__restrict__ scal, int etot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D) gc_out[i] = B[nmat + i];
+    if (i == 0) scal[etot] = B[nmat + D];
+}
+
+template <typename T> inline void ba_qr_backsolve(hipStream_t st, const T *A, size_t lda, int D, T *y)
+{
+    hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)(D + 64 + 64 * 64), st, A, lda, D, y);
+}
+
+template <typename T>
+inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, hipStream_t st2 = nullptr,
+                         hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
 {
     constexpr int NSB1 = ba_qr_cfg<T>::NSB, NSBU = ba_qr_cfg<T>::NSBU;
     const bool two = st2 != nullptr && ev_chunk != nullptr && ev_apply != nullptr;
@@ -570,7 +602,14 @@ inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *t
             (void)hipStreamWaitEvent(st, ev_apply, 0);
         }
     }
-    hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)(D + 64 + 64 * 64), st, (const T *)A, lda, D, y);
+}
+
+template <typename T>
+inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, hipStream_t st2 = nullptr,
+                        hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
+{
+    ba_qr_factor<T>(st, A, lda, mrows, D, tau, tau_level_stride, st2, ev_chunk, ev_apply);
+    ba_qr_backsolve<T>(st, (const T *)A, lda, D, y);
 }
 
 #endif

@@ -83,7 +83,6 @@ struct SolverBase {
     virtual int minimize(const ba_lm_params *lm, ba_trial_cb cb, void *user, ba_result *out) = 0;
     virtual int time_phase(int phase, int reps, double lambda, double *ms) = 0;
     virtual int selftest(int which) = 0;
-    bool unshardable = false; // QRKIT / QRSPQR
     bool poisoned = false; // the watchdog gave up on a launch that never finished: every later call fails, nothing is freed
     int recoveries = 0;    // trials repeated through the launch-per-step factorisation after a hand-off time-out
     ba_allreduce_fn ar_fn = nullptr;
@@ -141,9 +140,13 @@ template <typename T> struct Solver final : SolverBase {
     hipStream_t st_qr = nullptr;   // second stream of the dense QR: trailing updates beside the panel's chunk chain (ba_qr_solve)
     hipEvent_t ev_qr[2] = {nullptr, nullptr};
     int q_rows = 0;
-    // QRKIT / QRSPQR always run the dense QR of J2bot: a sharded solve on these symbols is REFUSED (ba_solver_create,
-    // ba_solver_comm_init, ba_solver_set_allreduce), never silently turned into QRCHOL's normal equations
+    // QRKIT / QRSPQR always run the dense QR of J2bot -- sharded too (distributed TSQR: launch_qr_stack), never QRCHOL's normal
+    // equations under another name
     bool dense_qr() const { return kind == BA_QRKIT || kind == BA_QRSPQR; }
+    DevBuf<T> d_qB; // sharded: the stack of the shards' R factors (+ rhs column), behind it g_c and the energy (one all-reduce)
+    size_t qb_ld() const { return (size_t)world * D + 64; }
+    size_t qb_nmat() const { return qb_ld() * (size_t)(D + 1); }
+    size_t qb_count() const { return qb_nmat() + (size_t)D + 1; }
     ba_lm_host *h_log = nullptr, *d_log = nullptr; // table rows + progress counter in pinned host memory (host / device address)
     T h_scal[NSCAL];
     T *h_lam = nullptr; // pinned staging word for lambda
@@ -187,7 +190,6 @@ template <typename T> struct Solver final : SolverBase {
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
     {
         kind = k; rank = rk; world = wd;
-        unshardable = k == BA_QRKIT || k == BA_QRSPQR;
         int rc = ba_build_structure(p, rk, wd, BA_CHUNK, 32 /* lanes of a k_cam_gram group */, &sx);
         if (rc) return rc;
         N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
@@ -338,8 +340,9 @@ template <typename T> struct Solver final : SolverBase {
                 for (auto &e : ev_qr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             q_lda = (size_t)q_rows + 64;
-            q_tau_stride = (size_t)((q_rows + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB * BA_QR_PB; // a 32 x 32 T factor per chunk
+            q_tau_stride = (size_t)((std::max(q_rows, world * D) + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB * BA_QR_PB; // a 32 x 32 T factor per chunk (of J2bot's rows or, sharded, of the stack's)
             AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, 8 * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
+            if (world > 1) AL(d_qB, qb_count());
         }
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
         AL(d_rec, (size_t)BA_REC * K1); AL(d_dinv, 3 * M1); AL(d_tvec, 3 * M1); AL(d_tri, 6 * M1);
@@ -537,13 +540,33 @@ template <typename T> struct Solver final : SolverBase {
         (void)hipMemsetAsync(d_qA.p, 0, sizeof(T) * d_qA.n, st);
         const int nthr = std::max(Kl, D);
         hipLaunchKernelGGL((k_qrkit_build<T>), dim3((nthr + 255) / 256), dim3(256), 0, st, Kl, Ml, D, d_obs_cam.p, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_r.p,
-                           d_rec.p, d_q1obs.p, d_q1lam.p, d_tvec.p, d_scal.p + SC_LAMBDA, d_qA.p, q_lda);
+                           d_rec.p, d_q1obs.p, d_q1lam.p, d_tvec.p, d_scal.p + SC_LAMBDA, d_qA.p, q_lda, rank == 0 ? 1 : 0);
     }
     void launch_qrkit_solve()
     {
         ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p, st_qr, ev_qr[0], ev_qr[1]);
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
+    // Sharded QRKIT (distributed TSQR, ba_qr.hip.h): the QR of this shard's rows, its R + rhs head into the zeroed stack ...
+    int launch_qr_stack_pack()
+    {
+        int rc;
+        if (!d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
+        ba_qr_factor<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, st_qr, ev_qr[0], ev_qr[1]);
+        HIPCHK(hipMemsetAsync(d_qB.p, 0, sizeof(T) * qb_nmat(), st));
+        hipLaunchKernelGGL((k_qr_stack_pack<T>), dim3(D + 2), dim3(256), 0, st, (const T *)d_qA.p, q_lda, D, rank, d_qB.p, qb_ld(), qb_nmat(), (const T *)d_gc.p,
+                           (const T *)d_scal.p, (int)SC_ELOC);
+        return BA_OK;
+    }
+    // ... and, behind the all-reduce, the QR of the stack and the camera step (redundantly on every shard)
+    void launch_qr_stack_solve()
+    {
+        hipLaunchKernelGGL((k_qr_stack_unpack<T>), dim3((D + 255) / 256), dim3(256), 0, st, (const T *)d_qB.p, qb_nmat(), D, d_gcg.p, d_scal.p, (int)SC_ENERGY);
+        ba_qr_solve<T>(st, d_qB.p, qb_ld(), world * D, D, d_qtau.p, q_tau_stride, d_dxc.p, st_qr, ev_qr[0], ev_qr[1]);
+    }
+    // what the exchange step of a sharded trial sums: the packed reduced camera system, or (QRKIT / QRSPQR) the stack of R factors
+    T *xchg_ptr() { return dense_qr() ? d_qB.p : d_pack.p; }
+    size_t xchg_count() const { return dense_qr() ? qb_count() : pack_count() + 1; }
 
     void launch_factor()
     {
@@ -613,15 +636,15 @@ template <typename T> struct Solver final : SolverBase {
     int launch_seg_a()
     {
         launch_eliminate();
-        if (dense_qr()) { launch_qrkit_build(); return BA_OK; }
+        if (dense_qr()) { launch_qrkit_build(); return sharded() ? launch_qr_stack_pack() : BA_OK; }
         launch_schur();
         return sharded() ? launch_pack(false) : BA_OK;
     }
     int launch_seg_b()
     {
         int rc;
-        if (sharded() && (rc = launch_pack(true))) return rc;
-        if (dense_qr()) launch_qrkit_solve();
+        if (sharded() && !dense_qr() && (rc = launch_pack(true))) return rc;
+        if (dense_qr()) { if (sharded()) launch_qr_stack_solve(); else launch_qrkit_solve(); }
         else { launch_post_reduce(); launch_factor_solve(); }
         launch_backsub_retract();
         launch_test_energy();
@@ -647,10 +670,11 @@ template <typename T> struct Solver final : SolverBase {
         if (dense_qr()) launch_qrkit_build(); else launch_schur();
         HIPCHK(hipEventRecord(ev[EV_T2], st));
         if (sharded()) {
-            if ((rc = launch_pack(false)) || (rc = allreduce(d_pack.p, pack_count() + 1, 0)) || (rc = launch_pack(true))) return rc;
+            if (dense_qr()) { if ((rc = launch_qr_stack_pack()) || (rc = allreduce(d_qB.p, qb_count(), 0))) return rc; }
+            else if ((rc = launch_pack(false)) || (rc = allreduce(d_pack.p, pack_count() + 1, 0)) || (rc = launch_pack(true))) return rc;
         }
         HIPCHK(hipEventRecord(ev[EV_T3], st));
-        if (dense_qr()) launch_qrkit_solve();
+        if (dense_qr()) { if (sharded()) launch_qr_stack_solve(); else launch_qrkit_solve(); }
         else {
             launch_post_reduce();
             if (keep) {
@@ -864,7 +888,7 @@ template <typename T> struct Solver final : SolverBase {
         {
             if ((rc = run_seg(&g_a, &Solver::launch_seg_a, graphs))) return rc;
             HIPCHK(hipEventRecord(e.e[1], st));
-            if ((rc = allreduce(d_pack.p, pack_count() + 1, 0))) return rc; // reduced camera system + rhs + g_c + energy tail
+            if ((rc = allreduce(xchg_ptr(), xchg_count(), 0))) return rc; // reduced camera system (or stack of R factors) + rhs + g_c + energy tail
             HIPCHK(hipEventRecord(e.e[2], st));
             if ((rc = run_seg(&g_b, &Solver::launch_seg_b, graphs))) return rc;
             HIPCHK(hipEventRecord(e.e[3], st));
@@ -922,7 +946,8 @@ template <typename T> struct Solver final : SolverBase {
             h.fun_evals = 1;
             h.lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
         }
-        if (!h.stop && sharded() && !d_pack.p && (rc = d_pack.alloc(pack_count() + 1))) return rc; // (never inside a stream capture)
+        if (!h.stop && sharded() && !dense_qr() && !d_pack.p && (rc = d_pack.alloc(pack_count() + 1))) return rc; // (never inside a stream capture)
+        if (!h.stop && sharded() && dense_qr() && !d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
         if (!h.stop) {
             h_log->done = 0; h_log->stop = 0; h_log->status = BA_RUNNING;
             if ((rc = set_lambda(h.lambda))) return rc;
@@ -1169,13 +1194,6 @@ int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar,
     if (!p || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return BA_ERR_ARG;
     if (kind != BA_QRKIT && kind != BA_QRCHOL && kind != BA_CHOLESKY && kind != BA_MOREQR && kind != BA_QRSPQR) return BA_ERR_ARG;
     if (scalar != BA_F64 && scalar != BA_F32) return BA_ERR_ARG;
-    if ((kind == BA_QRKIT || kind == BA_QRSPQR) && shard_world > 1) {
-        // These symbols exist for the dense QR of J2bot (no normal equations: cond(J2bot) = sqrt(cond(S))).  The exchange step of the
-        // sharded path sums the reduced camera MATRIX, i.e. it would have to square J2bot after all -- QRCHOL under another name.
-        fprintf(stderr, "ba_mi355x: the QRKIT / QRSPQR symbols do not shard (their right block is a dense QR of J2bot, not the all-reduced "
-                        "normal equations): use QRCHOL, CHOLESKY or MOREQR with shard_world > 1\n");
-        return BA_ERR_ARG;
-    }
     *out = nullptr;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
@@ -1208,17 +1226,9 @@ void ba_solver_free(ba_solver *s)
 
 int ba_solver_recoveries(const ba_solver *s) { return s ? s->impl->recoveries : -1; }
 
-static bool ba_kind_does_not_shard(const ba_solver *s, const char *what)
-{
-    if (!s->impl->unshardable) return false;
-    fprintf(stderr, "ba_mi355x: %s refused: the QRKIT / QRSPQR symbols do not shard (dense QR of J2bot, no all-reduced normal equations)\n", what);
-    return true;
-}
-
 int ba_solver_set_allreduce(ba_solver *s, ba_allreduce_fn fn, void *user)
 {
     if (!s) return BA_ERR_ARG;
-    if (fn && ba_kind_does_not_shard(s, "ba_solver_set_allreduce")) return BA_ERR_ARG;
     s->impl->ar_fn = fn; s->impl->ar_user = user;
     return BA_OK;
 }
@@ -1227,7 +1237,6 @@ int ba_solver_comm_init(ba_solver *s, const void *id)
 {
     if (!s || !id) return BA_ERR_ARG;
     if (s->impl->comm) return BA_ERR_ARG;
-    if (ba_kind_does_not_shard(s, "ba_solver_comm_init")) return BA_ERR_ARG; // (a one-rank communicator too: the path would change)
     return ba_rccl_init(&s->impl->comm, id, s->impl->rank, s->impl->world);
 }
 

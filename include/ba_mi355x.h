@@ -42,8 +42,9 @@ enum {
  * blocks first and is left with one dense front, J2bot -- which is the factorisation the QRKIT path performs, so the symbol runs
  * that path (per-point Householder QR, dense Householder QR of J2bot); same LM loop as QRKIT (Eigen::BacktrackLevMarq).  The
  * equivalence is tested against a whole-matrix Householder QR with no block elimination (tests: test_qrspqr_against_the_whole_matrix_qr).
- * BA_QRKIT and BA_QRSPQR do NOT shard: ba_solver_create with shard_world > 1, ba_solver_comm_init and ba_solver_set_allreduce return
- * BA_ERR_ARG for them (the sharded exchange sums the reduced camera matrix -- the normal equations these symbols exist to avoid). */
+ * Sharded (shard_world > 1), BA_QRKIT and BA_QRSPQR keep their dense QR: every shard factors its own rows of J2bot, the exchange step
+ * sums a zeroed stack into which each shard has put its D x D triangle R (+ the head of Q^T rhs, g_c, energy), and the QR of the stack
+ * runs redundantly (distributed TSQR) -- never the normal equations these symbols exist to avoid. */
 typedef enum { BA_QRKIT = 0, BA_QRCHOL = 1, BA_CHOLESKY = 2, BA_MOREQR = 3, BA_QRSPQR = 4 } ba_solver_kind;
 
 /* `typedef double Scalar;` / `typedef float Scalar;` (src/BATypeUtils.h:6-7). */
@@ -151,8 +152,7 @@ int ba_comm_id_file_done(const char *path, int rank);
 /* Replaces the construction of BAFunctor + the LM object (bundle_adjustment_large.cpp:117-131): copies the problem
  * to HBM in SoA layout, builds the static camera-pair structure.  Points (and their observations) are partitioned
  * into shard_world contiguous ranges balanced by observation count; this handle owns range shard_rank.
- * device < 0 keeps the current HIP device. Fails with BA_ERR_HIP when no GPU is present, with BA_ERR_ARG for QRKIT / QRSPQR with
- * shard_world > 1 (those symbols do not shard, see ba_solver_kind) and when a QR symbol
+ * device < 0 keeps the current HIP device. Fails with BA_ERR_HIP when no GPU is present, with BA_ERR_ARG when a QR symbol
  * meets a point with more than 1024 observations (the per-point QR keeps a track in registers; CHOLESKY has no limit). */
 int ba_solver_create(const ba_problem *p, ba_solver_kind kind, ba_scalar scalar, int device, int shard_rank,
                      int shard_world, ba_solver **out);

@@ -178,21 +178,3 @@ def test_shard_plan_with_more_ranks_than_points(ba):
     assert plans[0]["p0"] == 0 and plans[-1]["p1"] == 5
     assert sum(q["o1"] - q["o0"] for q in plans) == 12 and sum(q["p1"] - q["p0"] for q in plans) == 5
     assert any(q["p1"] == q["p0"] for q in plans)  # some shards are empty: allowed
-
-
-def test_qrkit_and_qrspqr_refuse_to_shard(ba):
-    """ADVICE r2 / VERDICT r2 item 5b: a sharded QRKIT / QRSPQR solve used to run QRCHOL's normal equations under the QRKIT name,
-    silently.  The symbols now refuse: ba_solver_create(shard_world > 1) is an argument error (checked before any device is
-    touched, so this runs without a GPU); the other symbols get past that check (and fail on the missing GPU here, or succeed)."""
-    import ctypes as C
-    p = ba.Problem.synthetic(4, 30, 100, 1)
-    L = ba.lib()
-    for kind in (ba.QRKIT, ba.QRSPQR):
-        h = C.c_void_p()
-        assert L.ba_solver_create(p._h, kind, ba.F64, -1, 0, 2, C.byref(h)) == 4  # BA_ERR_ARG
-        assert not h.value
-    h = C.c_void_p()
-    rc = L.ba_solver_create(p._h, ba.QRCHOL, ba.F64, -1, 0, 2, C.byref(h))
-    assert rc in (0, 5)  # BA_OK on a GPU box, BA_ERR_HIP without a device -- not an argument error
-    if rc == 0:
-        L.ba_solver_free(h)

@@ -125,7 +125,7 @@ def test_two_ranks_natural_stop_same_number_of_collectives(ba, gpu_ok):
     assert abs(e0 - ref["energy"]) < 3e-2 * ref["energy"]
 
 
-@pytest.mark.parametrize("kind", [2, 1, 3])
+@pytest.mark.parametrize("kind", [2, 1, 3, 0])  # (0 = QRKIT: distributed TSQR -- the shards' R factors are what is all-reduced, no normal equations)
 @pytest.mark.timeout(600)
 def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
     p = ba.Problem.synthetic(24, 3000, 10500, 77)
@@ -150,7 +150,7 @@ def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
     assert np.allclose(trace[:, 2], ref["trace"][:, 2], rtol=3e-2)
 
 
-@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("kind", [2, 1, 0])
 @pytest.mark.timeout(300)
 def test_rccl_inside_library_one_rank(ba, gpu_ok, kind):
     """ba_comm_unique_id + ba_solver_comm_init (ncclCommInitRank inside the library) on a one-rank communicator switches ba_minimize
@@ -164,8 +164,11 @@ def test_rccl_inside_library_one_rank(ba, gpu_ok, kind):
     s.comm_init(ba.comm_unique_id())
     r = s.minimize(max_trials=NTR)
     assert r["status"] == ref["status"] and r["trials"] == ref["trials"] == NTR
-    assert np.array_equal(r["trace"][:, :5], ref["trace"][:, :5])
-    assert r["energy"] == ref["energy"]
+    if kind == 0:  # (QRKIT: the QR of the one-block "stack" re-triangularises R: same step up to rounding, not bit for bit)
+        assert np.array_equal(r["trace"][:, :2], ref["trace"][:, :2]) and np.allclose(r["trace"][:, 2:5], ref["trace"][:, 2:5], rtol=1e-6)
+    else:
+        assert np.array_equal(r["trace"][:, :5], ref["trace"][:, :5])
+        assert r["energy"] == ref["energy"]
     tm = s.timing()
     assert tm["n_graph_trials"] == NTR and tm["comm_ms"] > 0
     # the step-level seam goes through the same transport
@@ -187,19 +190,3 @@ def test_empty_shard_does_not_fault(ba, gpu_ok):
         assert e == 0.0
         et, rs, dn = s.try_step(1.0)
         assert et == 0.0 and np.isfinite(rs) and np.isfinite(dn)
-
-
-def test_qrkit_refuses_a_communicator(ba, gpu_ok, capfd):
-    """The other two ways into the sharded path are refused for QRKIT / QRSPQR as well (and say why): a communicator -- even of one
-    rank: the code path would change -- and a host transport."""
-    p = ba.Problem.synthetic(6, 100, 400, 3)
-    for kind in (ba.QRKIT, ba.QRSPQR):
-        s = ba.Solver(p, kind, ba.F64)
-        with pytest.raises(ba.BAError) as e1:
-            s.comm_init(b"\0" * 128)
-        with pytest.raises(ba.BAError) as e2:
-            s.set_allreduce(lambda *a: 0)
-        assert e1.value.code == 4 and e2.value.code == 4
-        e, _ = s.linearize()  # the solver is unharmed
-        assert np.isfinite(e)
-    assert "do not shard" in capfd.readouterr().err
