@@ -57,6 +57,21 @@ def algorithmic_bytes(N, M, K, S=8):
     return b_evalRJ, b_evalR, b_schur
 
 
+def pmc_traffic(workload, kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r03_pmc_<workload>.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in passes of their own -- they cannot ride on this run --, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950; profiles/r03_fetch_size_control.txt shows the doubling holds for this repo's gathers too).  None when the file is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)))[workload]
+    except Exception:
+        return None
+    for k, v in d.items():
+        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch_fetch_x2" in v:
+            return {"bytes_per_launch": v["hbm_bytes_per_launch_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_per_launch_raw"],
+                    "source": "profiles/r03_pmc_%s.json (%s, FETCH_SIZE x 2 + WRITE_SIZE)" % (workload, k)}
+    return None
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box hands a
     16-core share of a 256-thread host to each GPU)."""
@@ -212,17 +227,18 @@ def main():
         t_hbm = ph["eliminate"] + ph["schur_assembly"] + ph["backsub_retract"]
         secondary = {"bound": "hbm", "kernel": "k_elim_* + k_schur_pairs + k_schur_reduce + k_backsub", "achieved": by_hbm / (t_hbm * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm,
-                     "traffic": None}
+                     "traffic": pmc_traffic(args.workload, "k_schur_pairs")}
         if kind_s == "QRKIT":
             # the right block of this symbol is the dense Householder QR of J2bot, (2K + 3M + D) x D: 2 m D^2 flops on the vector /
-            # matrix units (fp32: the same rate), one k_qr_apply launch per (panel, TSQR level)
+            # matrix units (fp32: the same rate): per (panel, TSQR level) one k_qr_chunk launch (Householder, T factor) and one k_qr_apply
+            # launch (compact-WY trailing update on the matrix cores)
             mrows = 2 * K + 3 * M + D
             flops_qr = 2.0 * mrows * D * D
             peak = FP64_PEAK_TF if S == 8 else FP32_PEAK_TF
             ach = flops_qr / (ph["dense_factor"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_qr_chunk + k_qr_apply<%s> (blocked Householder QR of the dense %dx%d J2bot, TSQR panels; "
                                "peak = the fp%d matrix/vector rate)" % ("double" if S == 8 else "float", mrows, D, 8 * S),
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(args.workload, "k_qr_apply"),
                                "algorithmic_flops_per_trial": flops_qr, "ms_per_trial": ph["dense_factor"], "secondary": secondary}
         elif ph["dense_factor"] >= t_hbm:
             # k_ldlt_step (fused panel + trailing update; k_ldlt_panel for the first block column): nblk launches per trial,
@@ -230,9 +246,10 @@ def main():
             peak = FP64_PEAK_TF if S == 8 else FP32_PEAK_TF
             ach = flops_factor / (ph["dense_factor"] * 1e-3) / 1e12
             # traffic: HBM bytes need PMC passes of their own (rocprofv3 --pmc cannot ride on this run): scripts/evidence.sh collects
-            # them with this same command and profiles/ holds the result; the line itself carries no stale number
+            # them with this same command; the line quotes the committed per-launch figure and names its file
             out["roofline"] = {"bound": "mfma", "kernel": "k_ldlt_step<%s,64> (fused panel + trailing update of the dense LDL^T of the %dx%d reduced camera matrix; k_ldlt_panel for the first block column)" % ("double" if S == 8 else "float", D, D),
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": pmc_traffic(args.workload, "k_ldlt_step"),
                                "launches_per_trial": nblk, "avg_launch_us": 1e3 * ph["dense_factor"] / nblk,
                                "algorithmic_flops_per_launch": flops_factor / nblk, "ms_per_trial": ph["dense_factor"],
                                "secondary": secondary}
