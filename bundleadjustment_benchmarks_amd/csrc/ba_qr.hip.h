@@ -138,9 +138,9 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 }
 
 // ---- one chunk of a TSQR level: Householder QR of its rows of the panel, in registers --------------------------------------
-// Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them); the 32 panel columns are dealt to the four wavefronts of
-// the workgroup cyclically: wave w owns the columns 4 jq + w, jq = 0 .. 7, at the compile-time register positions jq (the step
-// loop is unrolled over jq: no register is ever moved).  Step j = 4 jq + jw: wave jw forms the reflector of its column jq (norm
+// Lane l holds rows l, l + 64, ... of the chunk (RPL = CH / 64 of them); the 32 panel columns are dealt to the eight wavefronts of
+// the workgroup cyclically: wave w owns the columns 8 jq + w, jq = 0 .. 3, at the compile-time register positions jq (the step
+// loop is unrolled over jq: no register is ever moved).  Step j = 8 jq + jw: wave jw forms the reflector of its column jq (norm
 // below the pivot by a wave reduction, the scalars redundantly in every lane), hands it to the others through LDS (double-buffered:
 // one barrier per step) and retires the column to memory (R entries above the pivot, beta on it, v below); then every wave updates
 // its columns behind j, one wave reduction per column for v . a_c.
@@ -150,18 +150,35 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 //   G = V^T V on the matrix cores (each wave its quarter of the rows, summed through LDS), then
 //   T(j, j) = tau_j,  T(0:j, j) = -tau_j T(0:j, 0:j) G(0:j, j)  -- one lane per row of T, 32 dependent steps --
 // written row-major to Tout[chunk][32][32] for k_qr_apply.
+// Scalars of a reflector.  float: the hardware square root and reciprocal (1 ulp) with one Newton step on the reciprocal -- the IEEE
+// sequences the compiler emits for `sqrtf` and `/` are ~40 instructions on the critical path of EVERY reflector step; a reflector's
+// beta and tau only have to be consistent with each other to working precision.  double: IEEE (the parity tests run in fp64).
+__device__ __forceinline__ float ba_qr_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double ba_qr_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float ba_qr_rcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double ba_qr_rcp(double x) { return 1.0 / x; }
+
+#define BA_QR_CWV 8 /* waves of a k_qr_chunk workgroup (two per SIMD: one's reductions and LDS round trips hide behind the other's FMAs) */
 template <typename T, int NSB>
-__global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
+__global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
                                                   T *__restrict__ Tout /* [chunks][32 * 32] */, int nch)
 {
-    constexpr int CH = BA_QR_PB * NSB, RPL = CH / 64, CW = BA_QR_PB / 4, RTW = CH / 64;
+    constexpr int NW = BA_QR_CWV, CH = BA_QR_PB * NSB, RPL = CH / 64, CW = BA_QR_PB / NW, RTW = CH / (16 * NW);
+    static_assert(RTW >= 1, "a wave owns at least one row tile of the Gram product");
     __shared__ T vs[2][CH];
     __shared__ T tj_s[2], taus[BA_QR_PB];
-    __shared__ T Gp[4][BA_QR_PB][BA_QR_PB + 1], Gs[BA_QR_PB][BA_QR_PB + 1]; // partial Gram matrices of the four waves; G, column j at Gs[j][.]
-    __shared__ __attribute__((aligned(16))) T St[4][16 * BA_QR_TP]; // per wave: a 16 x 32 tile of V between the load layout and the operand layout
+    __shared__ T Gp[NW][BA_QR_PB][BA_QR_PB + 1], Gs[BA_QR_PB][BA_QR_PB + 1]; // partial Gram matrices of the waves; G, column j at Gs[j][.]
+    __shared__ __attribute__((aligned(16))) T St[NW][16 * BA_QR_TP]; // per wave: a 16 x 32 tile of V between the load layout and the operand layout
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = blockIdx.x;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
     if (threadIdx.x < BA_QR_PB) taus[threadIdx.x] = (T)0;
+#ifdef BA_QR_STAMP
+    if (nch == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_stamp[36] = (long long)t_; }
+#endif
     T a[RPL][CW];
     size_t grow[RPL];
 #pragma unroll
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
         grow[e] = ba_qr_row<NSB>(row0, g, l < rows ? l : 0, stride);
 #pragma unroll
         for (int q = 0; q < CW; q++) {
-            const int c = 4 * q + wv;
+            const int c = NW * q + wv;
             a[e][q] = A[(size_t)(c0 + (c < bw ? c : 0)) * lda + grow[e]]; // (unconditional; masked below, behind ALL the loads)
         }
     }
@@ -179,61 +196,97 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
         const int l = lane + 64 * e;
 #pragma unroll
         for (int q = 0; q < CW; q++) {
-            const int c = 4 * q + wv;
+            const int c = NW * q + wv;
             T x = a[e][q];
             asm volatile("" : "+v"(x));
             a[e][q] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? x : (T)0;
         }
     }
+    // reflector of column j from this wave's register column `pos` (a compile-time position after unrolling): into the LDS buffer
+    // j & 1, the column retired to memory
+    auto form = [&](int pos, int j) {
+        T part = 0;
+#pragma unroll
+        for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][pos] * a[e][pos] : (T)0;
+        const T x2 = ba_wave_sum_all<T>(part);
+        const T alpha = ba_readlane_dyn(a[0][pos], j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
+        T tj = 0, sc = 0, beta = alpha;
+        if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
+            beta = ba_qr_sqrt(alpha * alpha + x2);
+            if (alpha > (T)0) beta = -beta;
+            tj = (beta - alpha) * ba_qr_rcp(beta);
+            sc = ba_qr_rcp(alpha - beta);
+        }
+        if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
+        // the hand-over first (the others wait for it), then the column's way to memory: a masked-out element goes to a scratch word
+        // (this chunk's T block, which the tail overwrites behind a full barrier) -- a select on the address instead of a branch per element
+        T keep[RPL];
+#pragma unroll
+        for (int e = 0; e < RPL; e++) {
+            const int l = lane + 64 * e;
+            const T ve = l > j ? a[e][pos] * sc : (l == j ? (T)1 : (T)0);
+            vs[j & 1][l] = ve;
+            keep[e] = l > j ? ve : (l == j ? beta : a[e][pos]);
+        }
+        T *const junk = Tout + (size_t)g * (BA_QR_PB * BA_QR_PB) + lane;
+#pragma unroll
+        for (int e = 0; e < RPL; e++) {
+            const int l = lane + 64 * e;
+            T *dst = (l < rows && (level == 1 || (l & 31) <= j)) ? A + (size_t)(c0 + j) * lda + grow[e] : junk;
+            *dst = keep[e]; // retire column j
+        }
+    };
+    // w_c = tau (v . a_c), a_c -= v w_c for the register columns q0 .. CW - 1 (v is 1 on its pivot row, zero above): all dot products
+    // first, then all wave reductions, then the updates -- the DPP chains of the columns interleave
+    auto update_from = [&](int q0, const T (&v)[RPL], T tj) {
+        T pd[CW];
+#pragma unroll
+        for (int q = q0; q < CW; q++) {
+            pd[q] = 0;
+#pragma unroll
+            for (int e = 0; e < RPL; e++) pd[q] += v[e] * a[e][q];
+        }
+#pragma unroll
+        for (int q = q0; q < CW; q++) pd[q] = tj * ba_wave_sum_all<T>(pd[q]);
+#pragma unroll
+        for (int q = q0; q < CW; q++)
+#pragma unroll
+            for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * pd[q];
+    };
+    // In-kernel stamps (scripts/bench_qr.hip -DBA_QR_STAMP, one-workgroup launch): 1.5 - 2.0 k cycles per step at 512 rows, of which a
+    // wave's update of its 3 - 4 live columns is 900 - 1400 (two waves share a SIMD's vector unit; 27 dependent-ish instructions per
+    // column: 8 FMAs, an 11-instruction DPP reduction, 8 FMAs) and the owner's reflector ~700.  Measured and not kept, all within 2 %:
+    // the next owner updating its column first and OWING the rest until behind the next barrier (so that the reflector forms beside
+    // the others' updates), v_readlane instead of the shuffle for the pivot, the hardware square root (which broke config 3).
     __syncthreads();
 #pragma unroll
     for (int jq = 0; jq < CW; jq++) {
 #pragma unroll 1
-        for (int jw = 0; jw < 4; jw++) {
-            const int j = 4 * jq + jw;
-            if (j >= bw) break; // (uniform; only the last panel is narrower than 32)
-            if (jw == wv) {     // (wave-uniform) this wave's column jq is column j
-                T part = 0;
-#pragma unroll
-                for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][jq] * a[e][jq] : (T)0;
-                const T x2 = ba_wave_sum_all<T>(part);
-                const T alpha = __shfl(a[0][jq], j, 64); // row j lives in lane j, e = 0 (j < 32)
-                T tj = 0, sc = 0, beta = alpha;
-                if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-                    beta = sqrt(alpha * alpha + x2);
-                    if (alpha > (T)0) beta = -beta;
-                    tj = (beta - alpha) / beta;
-                    sc = (T)1.0 / (alpha - beta);
-                }
-                if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
-#pragma unroll
-                for (int e = 0; e < RPL; e++) {
-                    const int l = lane + 64 * e;
-                    const T ve = l > j ? a[e][jq] * sc : (l == j ? (T)1 : (T)0);
-                    vs[j & 1][l] = ve;
-                    const T keep = l > j ? ve : (l == j ? beta : a[e][jq]);
-                    if (l < rows && (level == 1 || (l & 31) <= j)) A[(size_t)(c0 + j) * lda + grow[e]] = keep; // retire column j
-                }
-            }
-            __syncthreads();
+        for (int jw = 0; jw < NW; jw++) {
+            const int j = NW * jq + jw;
+            if (j >= bw) break;            // (uniform; only the last panel is narrower than 32)
+            if (jw == wv) form(jq, j);     // (wave-uniform) this wave's column jq is column j
+            // LDS-only barrier: the hand-over goes through LDS; __syncthreads() would also wait for the owner's global stores of the
+            // retired column
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef BA_QR_STAMP
+            long long t_exit = 0;
+            if (nch == 1) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); t_exit = (long long)t_; if (threadIdx.x == 0) ba_qr_stamp[j] = t_exit; }
+#endif
             const T tj = tj_s[j & 1];
             T v[RPL];
 #pragma unroll
             for (int e = 0; e < RPL; e++) v[e] = vs[j & 1][lane + 64 * e];
-            // w_c = tau (v . a_c) for this wave's columns behind j, a_c -= v w_c  (v is 1 on row j, zero above)
-#pragma unroll
-            for (int q = jq; q < CW; q++) {
-                if (q > jq || wv > jw) { // (wave-uniform) column 4 q + wv > j
-                    T pd = 0;
-#pragma unroll
-                    for (int e = 0; e < RPL; e++) pd += v[e] * a[e][q];
-                    const T w = tj * ba_wave_sum_all<T>(pd);
-#pragma unroll
-                    for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * w;
-                }
-            }
+            if (wv > jw) update_from(jq, v, tj);              // column NW jq + wv > j: register columns jq .. CW - 1 are live
+            else if (jq + 1 < CW) update_from(jq + 1, v, tj); // column jq of this wave is retired (or being retired)
+#ifdef BA_QR_STAMP
+            if (nch == 1 && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_busy[8 * j + wv] = (long long)t_ - t_exit; }
+#endif
         }
     }
+#ifdef BA_QR_STAMP
+    if (nch == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_stamp[32] = (long long)t_; }
+#endif
     // ---- T factor.  The retired columns are in memory (written by different waves of this workgroup: visible behind the barrier).
     __syncthreads();
     {
@@ -287,9 +340,12 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < BA_QR_PB * BA_QR_PB; idx += 256) {
+    for (int idx = threadIdx.x; idx < BA_QR_PB * BA_QR_PB; idx += 64 * NW) {
         const int k = idx >> 5, j = idx & 31;
-        Gs[j][k] = (Gp[0][k][j] + Gp[1][k][j]) + (Gp[2][k][j] + Gp[3][k][j]);
+        T sum = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) sum += Gp[w][k][j];
+        Gs[j][k] = sum;
     }
     __syncthreads();
     if (wv == 0) {
@@ -309,6 +365,9 @@ __global__ __launch_bounds__(256) void k_qr_chunk(T *__restrict__ A, size_t lda,
 #pragma unroll
             for (int k = 0; k < BA_QR_PB; k++) to[k] = Trow[k];
         }
+#ifdef BA_QR_STAMP
+        if (nch == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_stamp[33] = (long long)t_; }
+#endif
     }
 }
 
@@ -577,8 +636,8 @@ inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *
             const int fan = level == 1 ? NSB1 : NSBU;
             const int nch = (nsb + fan - 1) / fan;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
-            if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
-            else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(256), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
             if (nct > 0) {
                 hipStream_t sa = st;
                 if (two) {
