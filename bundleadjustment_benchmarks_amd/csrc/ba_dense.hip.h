@@ -891,11 +891,13 @@ __device__ __attribute__((noinline)) void ba_update_quad_call(int ld, int p0, in
 
 // Stand-alone trailing update (one launch per block column; kept for the non-fused path and the dense bench).
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int ld, int p0, T *__restrict__ S, const T *__restrict__ Wp)
+__global__ __launch_bounds__(256) void k_ldlt_update(int nrows, int ncols, int ld, int p0, T *__restrict__ S, const T *__restrict__ Wp,
+                                                     int owners = 1, int owner = 0 /* distributed factor: only the block columns q with q % owners == owner */)
 {
     const int p1 = p0 + NB;
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
+    if (owners > 1 && (p1 / NB + tj) % owners != owner) return;
     const int row0 = p1 + 64 * ti, col0 = p1 + 64 * tj;
     if (row0 >= nrows || col0 >= ncols) return;
     ba_update_tile<T, NB, false>(ld, p0, row0, col0, ti == tj, S, Wp, nullptr);
@@ -1071,12 +1073,16 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 {
     static_assert(NB == 64, "written for 64-wide block columns");
     __shared__ T zs[2 * NB], xin[2 * NB], xs[2 * NB], part[4][NB], part2[2][2 * NB];
+    const int wg = blockIdx.x, nwg = gridDim.x;
     // TWO workgroups per group.  A workgroup pulls the 128 KB block of L of every later group through one CU (~50 GB/s: 2.6 us per
     // block), and a hop of the chain could not be shorter than that.  The later groups are dealt to the two by the parity of their
     // distance: the main workgroup (role 0) takes g + 1, g + 3, ... -- the last one to arrive among them -- and solves the group;
     // the helper (role 1) takes g + 2, g + 4, ..., so it is done one hop BEFORE the chain reaches the group and hands its partial
     // sums over (zh, same sentinel protocol as x) off the critical path.  Each now needs a block every second hop.
-    const int tid = threadIdx.x, g = blockIdx.x >> 1, role = blockIdx.x & 1, G = gridDim.x >> 1;
+    // The LAST group goes first in dispatch order: a group waits for the groups behind it only, so every wait is for a workgroup that
+    // was dispatched earlier -- the sweep makes progress whether or not the whole grid is resident at once.
+    // (and a group's helper in front of its main workgroup, which waits for the helper's partial sums)
+    const int tid = threadIdx.x, G = nwg >> 1, g = G - 1 - (wg >> 1), role = (wg & 1) ^ 1;
     if (g == skip_group) return;
     const bool odd = (nblk & 1) != 0;
     const int fb = odd ? max(0, 2 * g - 1) : 2 * g, nbg = (odd && g == 0) ? 1 : 2; // first block column / block columns of this group

@@ -828,12 +828,34 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wav
 // diagonal blocks in full); pairs without any entry get their zero (or J_c^T J_c) block here too.  Row D of S receives the reduced rhs, row D+1 the camera gradient g_c (both travel through the
 // same all-reduce as S when the problem is sharded).  lambda I is added later by k_post_reduce (once, after the sum
 // over shards).
+// Single shard (lam != nullptr): there is no sum over shards to wait for, so k_post_reduce's work rides on this launch -- lambda
+// goes onto the diagonal where the diagonal blocks are written (always here: the host never marks a diagonal pair BA_CHUNK_SINGLE;
+// same order of additions as k_post_reduce: (V - s) + lambda), row D + 1 is not written at all, and `post_blocks` more workgroups
+// at the end of the grid copy g_c out, clear the rows below the rhs row, give the padding its unit diagonal and arm the backward
+// sweep's vectors.
 template <typename T>
 __global__ __launch_bounds__(192) void k_schur_reduce(int nred, const int *__restrict__ red_pairs, int D, int ld, const int *__restrict__ pair_hi,
                                                       const int *__restrict__ pair_lo, const int *__restrict__ pair_chunk_ptr,
                                                       const T *__restrict__ slab, const T *__restrict__ V,
-                                                      const T *__restrict__ gc, T *__restrict__ S)
+                                                      const T *__restrict__ gc, T *__restrict__ S, const T *__restrict__ lam = nullptr,
+                                                      int post_blocks = 0, int Dp = 0, T *__restrict__ gc_out = nullptr, T *__restrict__ xarm = nullptr)
 {
+    if (post_blocks && blockIdx.x >= gridDim.x - post_blocks) { // one wave per column (k_post_reduce's layout)
+        const int c = (blockIdx.x - (gridDim.x - post_blocks)) * 3 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (c >= Dp) return;
+        T *col = S + (size_t)c * ld;
+        if (lane == 0) {
+            xarm[c] = ba_sentinel<T>();
+            xarm[Dp + c] = ba_sentinel<T>();
+            if (c < D) gc_out[c] = gc[c];
+        }
+        if (c < D) {
+            for (int rr = D + 1 + lane; rr < Dp; rr += 64) col[rr] = 0;
+        } else {
+            for (int rr = c + lane; rr < Dp; rr += 64) col[rr] = (rr == c) ? (T)1 : (T)0;
+        }
+        return;
+    }
     const int idx = blockIdx.x * 192 + threadIdx.x;
     const int q = idx / BA_SLAB, e = idx - q * BA_SLAB;
     if (q >= nred || e >= 90) return;
@@ -853,12 +875,13 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int nred, const int *__res
         const int rr = e / 9, cc = e - 9 * rr;
         T v = -s;
         if (hi == lo) v += V[(size_t)hi * 81 + e];
+        if (lam && hi == lo && rr == cc) v += *lam;
         S[(size_t)(9 * lo + cc) * ld + 9 * hi + rr] = v;
     } else {
         const int cc = e - 81;
         const T g = gc[9 * hi + cc];
         S[(size_t)(9 * hi + cc) * ld + D] = g - s;
-        S[(size_t)(9 * hi + cc) * ld + D + 1] = g;
+        if (!lam) S[(size_t)(9 * hi + cc) * ld + D + 1] = g;
     }
 }
 
@@ -1078,10 +1101,29 @@ struct ba_lm_host { int done, stop, status, pad; ba_lm_row rows[BA_LM_RING]; };
 // indices into scal[]; guard: the slot that rides on the scalar all-reduce with every shard's previous decision (world = summands)
 struct ba_lm_slots { int energy, etest, rho_p, rho_c, dn_p, dn_c, lambda, err, guard, world; };
 
+// jobs (njobs > 0, single shard): the second stage of the trial's scalar reductions runs at the head of this launch instead of in a
+// k_reduce_scalars launch of its own (same 256-thread order, so the sums are the same bits); sharded runs keep that launch, the
+// all-reduce of the step scalars sits between the two.
+#define BA_LM_JOBS 3 /* sum jobs k_lm_control can take: 256 threads each */
 template <typename T>
-__global__ __launch_bounds__(64) void k_lm_control(T *__restrict__ scal, ba_lm_dev<T> *__restrict__ lm, ba_lm_host *__restrict__ host, ba_lm_slots sl)
+__global__ __launch_bounds__(256 * BA_LM_JOBS) void k_lm_control(T *__restrict__ scal, ba_lm_dev<T> *__restrict__ lm, ba_lm_host *__restrict__ host,
+                                                                 ba_lm_slots sl, ba_red_jobs jobs, int njobs)
 {
-    if (threadIdx.x != 0) return;
+    if (njobs > 0) { // 256 threads per job, side by side, each group in the order of a k_reduce_scalars block (ba_reduce_job, sum)
+        __shared__ T red[BA_LM_JOBS][4];
+        const int q = threadIdx.x >> 8, t = threadIdx.x & 255;
+        T a = 0;
+        if (q < njobs) {
+            const T *src = (const T *)jobs.j[q].src;
+            for (int k = t; k < jobs.j[q].n; k += 256) a += src[k];
+        }
+        a = wave_reduce<T, false>(a);
+        if ((t & 63) == 0) red[q][t >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < njobs; j++) scal[jobs.j[j].dst] = ((red[j][0] + red[j][1]) + red[j][2]) + red[j][3];
+    }
+    if (threadIdx.x != 0) return; // (thread 0 wrote the sums itself: it reads its own stores below)
     const long long now = (long long)wall_clock64();
     ba_lm_dev<T> s = *lm;
     if (s.stop) { // a trial enqueued behind the end of the run: it changes nothing

@@ -127,6 +127,7 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<int> d_wave_ptr;    // per wavefront of the pair kernel: its range of chunk descriptors
     DevBuf<int> d_red_pairs;   // pairs k_schur_reduce writes: those without entries and those with several chunks
     int nred = 0;
+    const bool no_fold = getenv("BA_NO_FOLD") != nullptr; // dev switch: every launch of its own again (A/B timing on one box)
     int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1;
     // state: x = d_cam[0], d_pts[0]; xTest = d_cam[1], d_pts[1] (x = xTest is a device-side copy, k_commit)
     // linearisation at x (r, J, J^T r, block diagonals, MOREQR's outer factors): one set
@@ -211,6 +212,7 @@ template <typename T> struct Solver final : SolverBase {
         memset((void *)h_log, 0, sizeof(ba_lm_host));
         HIPCHK(hipHostGetDevicePointer((void **)&d_log, (void *)h_log, 0));
         use_graph = getenv("BA_NO_GRAPH") == nullptr;
+        dist_factor = getenv("BA_DIST_FACTOR") != nullptr && atoi(getenv("BA_DIST_FACTOR")) != 0;
         if (const char *wd = getenv("BA_WATCHDOG_S")) { const double v = atof(wd); if (v > 0) watchdog_s = v; }
         {
             int dev = 0;
@@ -280,7 +282,8 @@ template <typename T> struct Solver final : SolverBase {
                 std::vector<int> cur(wptr.begin(), wptr.end() - 1);
                 for (int c = 0; c < sx.nchunks; c++) { // increasing chunk id inside every wavefront's list
                     const int q = sx.chunk_pair[c];
-                    const bool single = sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] == 1;
+                    // (a diagonal pair always goes through k_schur_reduce, which puts lambda on the diagonal when k_post_reduce is folded away)
+                    const bool single = sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] == 1 && sx.pair_hi[q] != sx.pair_lo[q];
                     ci[cur[owner[c]]++] = make_int4(sx.chunk_ptr[c], (sx.chunk_ptr[c + 1] - sx.chunk_ptr[c]) | (single ? BA_CHUNK_SINGLE : 0),
                                                     sx.pair_hi[q] | (sx.pair_lo[q] << 16), c);
                 }
@@ -288,7 +291,7 @@ template <typename T> struct Solver final : SolverBase {
             if ((rc = d_wave_ptr.upload(wptr))) return rc;
             std::vector<int> red;
             for (int q = 0; q < sx.npairs; q++)
-                if (sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] != 1) red.push_back(q);
+                if (sx.pair_chunk_ptr[q + 1] - sx.pair_chunk_ptr[q] != 1 || sx.pair_hi[q] == sx.pair_lo[q]) red.push_back(q);
             nred = (int)red.size();
             if ((rc = d_red_pairs.upload(red))) return rc;
             std::vector<int2> en((size_t)sx.E);
@@ -515,8 +518,13 @@ template <typename T> struct Solver final : SolverBase {
 #undef BA_QR
     }
 
+    // single shard: k_post_reduce's work rides on the two Schur launches (see k_schur_reduce)
+    bool post_folded() const { return !sharded() && nred > 0 && !no_fold; }
+    bool ctl_reduces() const { return !sharded() && !no_fold; }
+
     void launch_schur()
     {
+        const T *lamf = post_folded() ? d_scal.p + SC_LAMBDA : nullptr;
         if (sx.nchunks > 0) {
             // persistent: schur_wgs workgroups per CU, every wavefront walks its own balanced list of chunks (see k_schur_pairs)
             const dim3 gp(schur_grid);
@@ -527,11 +535,45 @@ template <typename T> struct Solver final : SolverBase {
 #undef BA_PAIRS
         }
         const long long nthr = (long long)nred * BA_SLAB;
+        const int post_blocks = lamf ? (Dp + 2) / 3 : 0;
         if (nred > 0)
-            hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192)), dim3(192), 0, st, nred, d_red_pairs.p, D, ld,
-                               d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p);
+            hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192) + post_blocks), dim3(192), 0, st, nred, d_red_pairs.p, D, ld,
+                               d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p, lamf, post_blocks, Dp, d_gcg.p, d_dxc.p);
     }
 
+    // ---- distributed factor (BA_DIST_FACTOR=1, sharded LDL^T symbols; SURVEY 8e "consider distributing K6" -- FUNCTIONAL, unmeasured: this
+    // pool gives one GPU).  1-D block-cyclic over the ranks: rank p % world owns block column p.  Per block column: the owner factors
+    // it (k_ldlt_panel: L into S, Y = L D into Wp, the block's inverse into Winv), the three pieces are broadcast as sum all-reduces
+    // over zeroed copies on the other ranks, and every rank applies the panel to the block columns IT owns (k_ldlt_update with the
+    // owner filter).  Behind the last column every rank holds the whole L and runs the back sweep redundantly.  The launch-per-step
+    // kernels: nobody waits for anybody inside a launch; three collectives per block column -- a design to measure once there is a
+    // node, not a speed claim (at D = 2313 the factor is latency-bound and every hop is on its critical path).
+    bool dist_factor = false;
+    int launch_factor_solve_dist()
+    {
+        const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
+        const size_t colsz = (size_t)ld * NB;
+        int rc;
+        for (int p = 0; p < nblk; p++) {
+            const int p0 = p * NB, below = nrows - (p0 + NB), npanel = below > 0 ? (below + 63) / 64 : 1;
+            T *wcol = d_Wp.p, *scol = d_S.p + (size_t)p0 * ld, *winv = d_Winv.p + (size_t)p * NB * NB;
+            if (p % world == rank)
+                hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, wcol, winv, (int *)nullptr, 0);
+            else {
+                HIPCHK(hipMemsetAsync(wcol, 0, sizeof(T) * colsz, st));
+                HIPCHK(hipMemsetAsync(scol, 0, sizeof(T) * colsz, st));
+                HIPCHK(hipMemsetAsync(winv, 0, sizeof(T) * NB * NB, st));
+            }
+            if ((rc = allreduce(wcol, colsz, 0)) || (rc = allreduce(scol, colsz, 0)) || (rc = allreduce(winv, (size_t)NB * NB, 0))) return rc;
+            const int p1 = p0 + NB;
+            if (p1 < ncols) {
+                const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
+                hipLaunchKernelGGL((k_ldlt_update<T, NB>), dim3(ntj, nti), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, (const T *)wcol, world, rank);
+            }
+        }
+        ba_ldlt_backsweep<T, NB>(st, D, ld, D, d_S.p, d_Winv.p, d_dxc.p, d_dxc.p + Dp, /*armed by k_post_reduce*/ true, num_cus, d_scal.p + SC_ERR, /*safe*/ true);
+        return BA_OK;
+    }
     void launch_factor_solve() { launch_factor(); launch_backsweep(); }
 
     // QRKIT's right block (BAFunctor.h:101): J2bot built densely, Householder QR (ba_qr.hip.h), dx_c from R y = -Q^T qtb2
@@ -583,6 +625,7 @@ template <typename T> struct Solver final : SolverBase {
 
     void launch_post_reduce()
     {
+        if (post_folded()) return;
         hipLaunchKernelGGL((k_post_reduce<T>), dim3((Dp + 3) / 4), dim3(256), 0, st, D, Dp, ld, d_scal.p + SC_LAMBDA, d_S.p, d_gcg.p, d_dxc.p);
     }
 
@@ -604,14 +647,19 @@ template <typename T> struct Solver final : SolverBase {
                                d_cam[1].p, d_scal.p, (int)SC_RHO_C);
     }
 
-    void launch_test_energy()
+    ba_red_jobs test_energy_jobs() const
     {
-        launch_eval(false, 1);
         ba_red_jobs jobs{};
         jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
         jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
         jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
-        hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, jobs, d_scal.p, (const int *)nullptr);
+        return jobs;
+    }
+    // reduce: false when the control kernel behind this trial sums the partials itself (launch_seg_ctl, single shard)
+    void launch_test_energy(bool reduce = true)
+    {
+        launch_eval(false, 1);
+        if (reduce) hipLaunchKernelGGL((k_reduce_scalars<T>), dim3(3), dim3(256), 0, st, test_energy_jobs(), d_scal.p, (const int *)nullptr);
     }
 
     // sharded: the block-lower trapezoid of S (matrix + rhs row + g_c row: half the bytes of the full buffer) + one tail scalar
@@ -645,16 +693,20 @@ template <typename T> struct Solver final : SolverBase {
         int rc;
         if (sharded() && !dense_qr() && (rc = launch_pack(true))) return rc;
         if (dense_qr()) { if (sharded()) launch_qr_stack_solve(); else launch_qrkit_solve(); }
-        else { launch_post_reduce(); launch_factor_solve(); }
+        else {
+            launch_post_reduce();
+            if (dist_factor && sharded()) { if ((rc = launch_factor_solve_dist())) return rc; }
+            else launch_factor_solve();
+        }
         launch_backsub_retract();
-        launch_test_energy();
+        launch_test_energy(!ctl_reduces()); // (single shard: k_lm_control sums the three partial arrays at its head)
         return BA_OK;
     }
     // step control on the device, x = xTest and the linearisation of the next outer iteration, the latter two conditional
     int launch_seg_ctl()
     {
         ba_lm_slots sl{SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR, SC_GUARD, world};
-        hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(64), 0, st, d_scal.p, d_lm.p, d_log, sl);
+        hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(256 * BA_LM_JOBS), 0, st, d_scal.p, d_lm.p, d_log, sl, test_energy_jobs(), ctl_reduces() ? 3 : 0);
         return linearize_enqueue(false, &d_lm.p->go); // (x = xTest happens inside its first kernel)
     }
 
@@ -681,7 +733,8 @@ template <typename T> struct Solver final : SolverBase {
                 if (!d_Skeep.p && (rc = d_Skeep.alloc(d_S.n))) return rc;
                 HIPCHK(hipMemcpyAsync(d_Skeep.p, d_S.p, sizeof(T) * d_S.n, hipMemcpyDeviceToDevice, st));
             }
-            launch_factor_solve();
+            if (dist_factor && sharded()) { if ((rc = launch_factor_solve_dist())) return rc; }
+            else launch_factor_solve();
         }
         HIPCHK(hipEventRecord(ev[EV_T4], st));
         launch_backsub_retract();
@@ -956,7 +1009,7 @@ template <typename T> struct Solver final : SolverBase {
             HIPCHK(hipMemcpyAsync(d_lm.p, &h, sizeof h, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st)); // (h is on the stack)
             // graphs unless the stream cannot be captured (legacy stream) or a host callback sits between the segments anyway
-            const bool graphs = use_graph && st != nullptr;
+            const bool graphs = use_graph && st != nullptr && !(dist_factor && sharded()); // (the distributed factor's collectives sit INSIDE segment B)
             auto tlast = std::chrono::steady_clock::now();
             auto drain = [&]() { // table rows that have appeared since the last look
                 const int done = __atomic_load_n(&h_log->done, __ATOMIC_ACQUIRE);

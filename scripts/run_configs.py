@@ -11,6 +11,18 @@ from conftest import to_oracle
 
 cfgs = sys.argv[1:] or ["cfg2", "cfg3", "cfg1", "cfg4"]
 rows = []
+
+
+def _heartbeat():  # (the oracle's free run at config 4 is minutes of silence: gpurun takes a silent command for hung)
+    import threading
+    def beat():
+        while True:
+            time.sleep(60)
+            print("... running (%s)" % time.strftime("%H:%M:%S"), file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_heartbeat()
 for name in cfgs:
     kind_s, scalar_s, _, _, _ = WORKLOADS[name]
     kind = {"QRKIT": ba.QRKIT, "QRCHOL": ba.QRCHOL, "CHOLESKY": ba.CHOLESKY}[kind_s]
