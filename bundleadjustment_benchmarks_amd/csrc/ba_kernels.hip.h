@@ -715,6 +715,24 @@ __device__ __forceinline__ float ba_bufload(__amdgpu_buffer_rsrc_t r, unsigned o
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
+// three consecutive scalars (a lane's row of Z, a point's 1 / D) with as few requests as the ISA allows: 16 + 8 bytes (fp64), 12 (fp32)
+typedef int ba_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned off, double &x0, double &x1, double &x2)
+{
+    const ba_v4i lo = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const ba_v2i hi = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off + 16), 0, 0);
+    x0 = __builtin_bit_cast(double, ba_v2i{lo.x, lo.y});
+    x1 = __builtin_bit_cast(double, ba_v2i{lo.z, lo.w});
+    x2 = __builtin_bit_cast(double, hi);
+}
+__device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned off, float &x0, float &x1, float &x2)
+{
+    // (three 4-byte requests inside ONE 128-byte line: a 12-byte load gave wrong sums here and was not pursued -- the fp32 record is
+    // a single cache line, there is no second request to save)
+    x0 = ba_bufload(r, off, (const float *)nullptr);
+    x1 = ba_bufload(r, off + 4, (const float *)nullptr);
+    x2 = ba_bufload(r, off + 8, (const float *)nullptr);
+}
 template <typename T, bool SCALED /* dinv != 1: CHOLESKY */>
 __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wave_ptr, int nband, const int4 *__restrict__ chunk_info,
                                                      const int2 *__restrict__ ent, const T *__restrict__ rec, unsigned rec_bytes,
@@ -764,12 +782,18 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wav
                 const unsigned ra = (unsigned)ia * RB, rb = (unsigned)(self ? ia : ibr) * RB;
                 const unsigned oa = (ok && la) ? ra + lane_off : OOB, ob = (ok && la) ? rb + lane_off : OOB;
                 const unsigned od = (ok && la) ? ra + BA_REC_DINV * SZ : OOB;
+#ifdef BA_SCHUR_NARROW_LOADS
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
                     o.a[3 * u + m] = ba_bufload(rsrc, oa + m * SZ, (const T *)nullptr);
                     if (SCALED) o.d[3 * u + m] = ba_bufload(rsrc, od + m * SZ, (const T *)nullptr);
                     o.b[3 * u + m] = ba_bufload(rsrc, ob + m * SZ, (const T *)nullptr);
                 }
+#else
+                ba_bufload3(rsrc, oa, o.a[3 * u], o.a[3 * u + 1], o.a[3 * u + 2]);
+                if (SCALED) ba_bufload3(rsrc, od, o.d[3 * u], o.d[3 * u + 1], o.d[3 * u + 2]);
+                ba_bufload3(rsrc, ob, o.b[3 * u], o.b[3 * u + 1], o.b[3 * u + 2]);
+#endif
                 if (diag && i == 9 && ok && self) { // column 9 of B: t of the point (reduced rhs)
 #pragma unroll
                     for (int m = 0; m < 3; m++) o.b[3 * u + m] = tvec[(size_t)m * Ml + (~ibr)];

@@ -126,6 +126,7 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<int2> d_ent;        // per entry: row observation, column observation (~point for a self entry)
     DevBuf<int> d_wave_ptr;    // per wavefront of the pair kernel: its range of chunk descriptors
     DevBuf<int> d_red_pairs;   // pairs k_schur_reduce writes: those without entries and those with several chunks
+    int schur_window = 0;
     int nred = 0;
     const bool no_fold = getenv("BA_NO_FOLD") != nullptr; // dev switch: every launch of its own again (A/B timing on one box)
     int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1;
@@ -229,6 +230,10 @@ template <typename T> struct Solver final : SolverBase {
         UP(d_cam_obs, sx.cam_obs); UP(d_qr_pts, sx.qr_pts);
 #undef UP
         {
+            // Records beyond the Infinity Cache (256 MB; config 5: 1 GB): the kernel is bound by the traffic between the L2s and
+            // memory, and fewer wavefronts in flight walking the pair list side by side leave more of a row camera's records in the
+            // L2 (2.23 -> 2.07 ms at config 5; nothing either way at config 4, whose 58 MB of records stay in the Infinity Cache).
+            if ((unsigned long long)Kl * BA_REC * sizeof(T) > (256ull << 20)) { schur_wgs = 2; schur_window = 1; }
             if (const char *ev = getenv("BA_SCHUR_WGS")) schur_wgs = std::max(1, std::min(8, atoi(ev)));
             if (const char *ev = getenv("BA_SCHUR_BANDS")) schur_bands = atoi(ev);
             // Chunks dealt to the wavefronts of the persistent pair kernel, longest first, always to the least loaded wavefront
@@ -260,19 +265,30 @@ template <typename T> struct Solver final : SolverBase {
                     while (b < nband && acc >= tot * b / nband) bptr[b++] = c + 1;
                 }
             }
+            // The dealing goes window by window through the band (schur_window chunks per wavefront and window; 0 = the whole band
+            // is one window): the loads carry over, so the balance is the same, but a wavefront's list now holds a few chunks of
+            // EVERY window, i.e. all wavefronts of the band walk through the (row camera, column camera) order side by side and the
+            // records of one row camera (its observations: ~1 MB at config 5) are in the XCD's L2 when the next column camera's
+            // chunk asks for them.
+            if (const char *ev = getenv("BA_SCHUR_WINDOW")) schur_window = std::max(0, atoi(ev));
             for (int b = 0; b < nband; b++) {
-                order.assign(bptr[b + 1] - bptr[b], 0);
-                std::iota(order.begin(), order.end(), bptr[b]);
-                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
                 typedef std::pair<long long, int> load_t; // (load, wavefront): min-heap
                 std::priority_queue<load_t, std::vector<load_t>, std::greater<load_t>> heap;
                 for (int w = 0; w < Wb; w++) heap.push(load_t(0, b * Wb + w));
-                for (int c : order) {
-                    load_t t = heap.top();
-                    heap.pop();
-                    owner[c] = t.second;
-                    wptr[t.second + 1]++;
-                    heap.push(load_t(t.first + cost(c), t.second));
+                const int nb_ = bptr[b + 1] - bptr[b];
+                const long long win = schur_window > 0 ? (long long)schur_window * Wb : (long long)std::max(nb_, 1);
+                for (long long w0 = bptr[b]; w0 < bptr[b + 1]; w0 += win) {
+                    const int w1 = (int)std::min<long long>(w0 + win, bptr[b + 1]);
+                    order.assign(w1 - (int)w0, 0);
+                    std::iota(order.begin(), order.end(), (int)w0);
+                    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+                    for (int c : order) {
+                        load_t t = heap.top();
+                        heap.pop();
+                        owner[c] = t.second;
+                        wptr[t.second + 1]++;
+                        heap.push(load_t(t.first + cost(c), t.second));
+                    }
                 }
             }
             schur_nband = nband;
