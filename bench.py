@@ -72,6 +72,15 @@ def pmc_traffic(workload, kernel_prefix):
     return None
 
 
+def with_traffic(roof, workload, kernel_prefix):
+    """roofline.traffic = HBM bytes per launch (a number, or null without a committed PMC pass); where it comes from beside it."""
+    t = pmc_traffic(workload, kernel_prefix)
+    roof["traffic"] = t["bytes_per_launch"] if t else None
+    if t:
+        roof["traffic_detail"] = t
+    return roof
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box hands a
     16-core share of a 256-thread host to each GPU)."""
@@ -226,8 +235,8 @@ def main():
         by_hbm = b_schur - 3 * D * D * S
         t_hbm = ph["eliminate"] + ph["schur_assembly"] + ph["backsub_retract"]
         secondary = {"bound": "hbm", "kernel": "k_elim_* + k_schur_pairs + k_schur_reduce + k_backsub", "achieved": by_hbm / (t_hbm * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm,
-                     "traffic": pmc_traffic(args.workload, "k_schur_pairs")}
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_hbm / (t_hbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by_hbm, "ms": t_hbm}
+        with_traffic(secondary, args.workload, "k_schur_pairs")
         if kind_s == "QRKIT":
             # the right block of this symbol is the dense Householder QR of J2bot, (2K + 3M + D) x D: 2 m D^2 flops on the vector /
             # matrix units (fp32: the same rate): per (panel, TSQR level) one k_qr_chunk launch (Householder, T factor) and one k_qr_apply
@@ -238,8 +247,9 @@ def main():
             ach = flops_qr / (ph["dense_factor"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_qr_chunk + k_qr_apply<%s> (blocked Householder QR of the dense %dx%d J2bot, TSQR panels; "
                                "peak = the fp%d matrix/vector rate)" % ("double" if S == 8 else "float", mrows, D, 8 * S),
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(args.workload, "k_qr_apply"),
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "algorithmic_flops_per_trial": flops_qr, "ms_per_trial": ph["dense_factor"], "secondary": secondary}
+            with_traffic(out["roofline"], args.workload, "k_qr_apply<float, 32" if S == 4 else "k_qr_apply<double, 16")
         elif ph["dense_factor"] >= t_hbm:
             # k_ldlt_step (fused panel + trailing update; k_ldlt_panel for the first block column): nblk launches per trial,
             # each processing 1/nblk of the D^3/3 flops on average
@@ -249,10 +259,10 @@ def main():
             # them with this same command; the line quotes the committed per-launch figure and names its file
             out["roofline"] = {"bound": "mfma", "kernel": "k_ldlt_step<%s,64> (fused panel + trailing update of the dense LDL^T of the %dx%d reduced camera matrix; k_ldlt_panel for the first block column)" % ("double" if S == 8 else "float", D, D),
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": pmc_traffic(args.workload, "k_ldlt_step"),
                                "launches_per_trial": nblk, "avg_launch_us": 1e3 * ph["dense_factor"] / nblk,
                                "algorithmic_flops_per_launch": flops_factor / nblk, "ms_per_trial": ph["dense_factor"],
                                "secondary": secondary}
+            with_traffic(out["roofline"], args.workload, "k_ldlt_step")
         else:
             out["roofline"] = secondary
         out["phase_replay_ms"] = ph
