@@ -585,9 +585,10 @@ __global__ __launch_bounds__(256) void k_qr_backsolve(const T *__restrict__ A, s
 // level, 8 levels (CH = 1024 / 512 rows: 181 633 rows are 3 levels in fp32, 4 in fp64).
 // st2 != nullptr (with two events): the trailing updates run on st2 beside the panel's chunk chain -- level L + 1 of the chain only
 // needs the panel's own R's from level L, not the trailing update of level L -- and the next panel waits for the last of them
-// (fork / join by events: also valid inside a stream capture).  6.2 -> 5.3 ms per trial at config 3.  With look-ahead on top (every
-// level's reflectors to the next panel's 32 columns first, on `st`, so that the next chain starts before the rest is done) it was
-// 5.7 ms: five more launches of one task's latency each on the critical stream cost more than the overlap gives.
+// (fork / join by events: also valid inside a stream capture).  6.2 -> 5.3 ms per trial at config 3 in round 2.  Look-ahead (every
+// level's reflectors to the next panel's 32 columns first, so that the next chain starts before the rest is done): on `st` itself it
+// cost more than it gave in round 2 (5.7 ms: five more launches on the critical stream); round 3 puts those launches on a THIRD
+// stream -- the chain stream carries nothing but the chunk kernels (ba_qr_side).
 // ---- sharded QRKIT: distributed TSQR ----------------------------------------------------------------------------------------------
 // Every shard factors the rows of J2bot it owns (ba_qr_factor); what it contributes to the whole matrix's factor is its D x D
 // triangle R_r and the head of Q_r^T rhs.  k_qr_stack_pack copies both into block r of a zeroed (world D) x (D + 1) matrix, behind
@@ -620,54 +621,90 @@ template <typename T> inline void ba_qr_backsolve(hipStream_t st, const T *A, si
     hipLaunchKernelGGL((k_qr_backsolve<T>), dim3(1), dim3(256), sizeof(T) * (size_t)(D + 64 + 64 * 64), st, A, lda, D, y);
 }
 
+// Side streams of the factorisation (all nullptr: everything on `st`).  st2 alone: the trailing updates beside the chunk chain.
+// st2 + st3 (look-ahead): a level's reflectors go to the NEXT panel's 32 columns on st3 and to the rest on st2; the next chain
+// waits for st3 only.
+#define BA_QR_TAU_LEVELS 8 /* TSQR levels the T storage has room for (16^8 chunks) */
+struct ba_qr_side {
+    hipStream_t st2 = nullptr, st3 = nullptr;
+    hipEvent_t ev_chunk = nullptr, ev_apply = nullptr, ev_next = nullptr; // chunk done (st) | rest updated (st2) | next panel updated (st3)
+    bool two() const { return st2 && ev_chunk && ev_apply; }
+    bool lookahead() const { return two() && st3 && ev_next; }
+};
+
 template <typename T>
-inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, hipStream_t st2 = nullptr,
-                         hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
+inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau_all, size_t tau_level_stride, const ba_qr_side &sd = ba_qr_side())
 {
+    // tau_all: BA_QR_TAU_LEVELS level slots of tau_level_stride scalars, TWICE with look-ahead: the chain of panel p + 1 writes its T
+    // factors while st2 still applies panel p's
     constexpr int NSB1 = ba_qr_cfg<T>::NSB, NSBU = ba_qr_cfg<T>::NSBU;
-    const bool two = st2 != nullptr && ev_chunk != nullptr && ev_apply != nullptr;
+    const bool two = sd.two(), la = sd.lookahead();
+    bool rest_pending = false, next_pending = false; // st2 / st3 hold updates that `st` (or the other one) has not waited for yet
+    auto apply = [&](hipStream_t sa, int level, int nch, int nsb, long long stride, const T *tl, int c0, int bw, int col0, int col1) {
+        const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB; // strips of 32 columns
+        // (8 x ceil(nch / 8) x nct workgroups: chunk g's strips sit at blockIdx % 8 == g % 8)
+        const dim3 ga((unsigned)(8ll * ((nch + 7) / 8) * nct));
+        if (level == 1)
+            hipLaunchKernelGGL((k_qr_apply<T, NSB1>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct);
+        else
+            hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct);
+    };
     for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
         const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
         const int col0 = c0 + bw, col1 = D + 1; // trailing columns incl. the right-hand side
+        const int colm = la ? (col0 + BA_QR_PB < col1 ? col0 + BA_QR_PB : col1) : col0; // look-ahead: [col0, colm) is the next panel
         int nsb = (mrows - c0 + BA_QR_PB - 1) / BA_QR_PB; // 32-row blocks from the panel's first row down
         long long stride = BA_QR_PB;
-        const int nct = (col1 - col0 + BA_QR_PB - 1) / BA_QR_PB; // strips of 32 trailing columns
+        T *tau = tau_all + (la && ((c0 / BA_QR_PB) & 1) ? (size_t)BA_QR_TAU_LEVELS * tau_level_stride : 0);
+        if (next_pending) { // this panel's columns carry every earlier reflector once st3 is done with them
+            (void)hipStreamWaitEvent(st, sd.ev_next, 0);
+            next_pending = false;
+        }
+        bool first_next = true;
         for (int level = 1;; level++) {
             const int fan = level == 1 ? NSB1 : NSBU;
             const int nch = (nsb + fan - 1) / fan;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
             if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
             else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
-            if (nct > 0) {
-                hipStream_t sa = st;
-                if (two) {
-                    (void)hipEventRecord(ev_chunk, st);
-                    (void)hipStreamWaitEvent(st2, ev_chunk, 0);
-                    sa = st2;
+            if (col0 < col1) {
+                if (two) (void)hipEventRecord(sd.ev_chunk, st);
+                if (la) {
+                    (void)hipStreamWaitEvent(sd.st3, sd.ev_chunk, 0);
+                    if (first_next && rest_pending) (void)hipStreamWaitEvent(sd.st3, sd.ev_apply, 0); // the previous panels' reflectors come first
+                    first_next = false;
+                    apply(sd.st3, level, nch, nsb, stride, (const T *)tl, c0, bw, col0, colm);
                 }
-                // (8 x ceil(nch / 8) x nct workgroups: chunk g's strips sit at blockIdx % 8 == g % 8)
-                const dim3 ga((unsigned)(8ll * ((nch + 7) / 8) * nct));
-                if (level == 1)
-                    hipLaunchKernelGGL((k_qr_apply<T, NSB1>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1, nch, nct);
-                else
-                    hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, (const T *)tl, col0, col1, nch, nct);
+                if (colm < col1) {
+                    if (two) (void)hipStreamWaitEvent(sd.st2, sd.ev_chunk, 0);
+                    apply(two ? sd.st2 : st, level, nch, nsb, stride, (const T *)tl, c0, bw, colm, col1);
+                }
             }
             if (nch == 1) break;
             nsb = nch;
             stride *= fan;
         }
-        if (two && nct > 0) { // the next panel (and the back substitution) read what the trailing updates wrote
-            (void)hipEventRecord(ev_apply, st2);
-            (void)hipStreamWaitEvent(st, ev_apply, 0);
+        if (two && colm < col1) {
+            (void)hipEventRecord(sd.ev_apply, sd.st2);
+            rest_pending = true;
+            if (!la) { // the next panel (and the back substitution) read what the trailing updates wrote
+                (void)hipStreamWaitEvent(st, sd.ev_apply, 0);
+                rest_pending = false;
+            }
+        }
+        if (la && col0 < col1) {
+            (void)hipEventRecord(sd.ev_next, sd.st3);
+            next_pending = true;
         }
     }
+    if (next_pending) (void)hipStreamWaitEvent(st, sd.ev_next, 0);
+    if (rest_pending) (void)hipStreamWaitEvent(st, sd.ev_apply, 0);
 }
 
 template <typename T>
-inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, hipStream_t st2 = nullptr,
-                        hipEvent_t ev_chunk = nullptr, hipEvent_t ev_apply = nullptr)
+inline void ba_qr_solve(hipStream_t st, T *A, size_t lda, int mrows, int D, T *tau, size_t tau_level_stride, T *y, const ba_qr_side &sd = ba_qr_side())
 {
-    ba_qr_factor<T>(st, A, lda, mrows, D, tau, tau_level_stride, st2, ev_chunk, ev_apply);
+    ba_qr_factor<T>(st, A, lda, mrows, D, tau, tau_level_stride, sd);
     ba_qr_backsolve<T>(st, (const T *)A, lda, D, y);
 }
 

@@ -140,7 +140,14 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<T> d_qA, d_qtau, d_q1obs, d_q1lam;
     size_t q_lda = 0, q_tau_stride = 0;
     hipStream_t st_qr = nullptr;   // second stream of the dense QR: trailing updates beside the panel's chunk chain (ba_qr_solve)
-    hipEvent_t ev_qr[2] = {nullptr, nullptr};
+    hipStream_t st_qr3 = nullptr;  // third one: the look-ahead updates (the next panel's columns)
+    hipEvent_t ev_qr[3] = {nullptr, nullptr, nullptr};
+    ba_qr_side qr_side() const
+    {
+        ba_qr_side sd;
+        sd.st2 = st_qr; sd.st3 = st_qr3; sd.ev_chunk = ev_qr[0]; sd.ev_apply = ev_qr[1]; sd.ev_next = ev_qr[2];
+        return sd;
+    }
     int q_rows = 0;
     // QRKIT / QRSPQR always run the dense QR of J2bot -- sharded too (distributed TSQR: launch_qr_stack), never QRCHOL's normal
     // equations under another name
@@ -186,6 +193,7 @@ template <typename T> struct Solver final : SolverBase {
         if (comm) ba_rccl_destroy(comm);
         if (own_stream && st) (void)hipStreamDestroy(st);
         if (st_qr) (void)hipStreamDestroy(st_qr);
+        if (st_qr3) (void)hipStreamDestroy(st_qr3);
         for (hipEvent_t e : ev_qr) if (e) (void)hipEventDestroy(e);
     }
 
@@ -356,11 +364,14 @@ template <typename T> struct Solver final : SolverBase {
             q_rows = 2 * Kl + 3 * Ml + D;
             if (!getenv("BA_QR_ONE_STREAM")) {
                 HIPCHK(hipStreamCreateWithFlags(&st_qr, hipStreamNonBlocking));
+                // (look-ahead on a third stream: measured, not the default -- 2.27 - 2.34 against 2.38 ms stand-alone, but 375 against
+                // 418 LM it/s inside the captured iteration graph, profiles/EXPERIMENTS.md 6.2)
+                if (getenv("BA_QR_LOOKAHEAD")) HIPCHK(hipStreamCreateWithFlags(&st_qr3, hipStreamNonBlocking));
                 for (auto &e : ev_qr) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             q_lda = (size_t)q_rows + 64;
             q_tau_stride = (size_t)((std::max(q_rows, world * D) + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB * BA_QR_PB; // a 32 x 32 T factor per chunk (of J2bot's rows or, sharded, of the stack's)
-            AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, 8 * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
+            AL(d_qA, q_lda * (size_t)(D + 1)); AL(d_qtau, (st_qr3 ? 2 : 1) * BA_QR_TAU_LEVELS * q_tau_stride); AL(d_q1obs, 6 * K1); AL(d_q1lam, 9 * M1);
             if (world > 1) AL(d_qB, qb_count());
         }
         AL(d_gcg, (size_t)D); AL(d_dslab, (size_t)BA_SLAB * (sx.ndchunks > 0 ? sx.ndchunks : 1));
@@ -602,7 +613,7 @@ template <typename T> struct Solver final : SolverBase {
     }
     void launch_qrkit_solve()
     {
-        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p, st_qr, ev_qr[0], ev_qr[1]);
+        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p, qr_side());
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
     // Sharded QRKIT (distributed TSQR, ba_qr.hip.h): the QR of this shard's rows, its R + rhs head into the zeroed stack ...
@@ -610,7 +621,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         if (!d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
-        ba_qr_factor<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, st_qr, ev_qr[0], ev_qr[1]);
+        ba_qr_factor<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, qr_side());
         HIPCHK(hipMemsetAsync(d_qB.p, 0, sizeof(T) * qb_nmat(), st));
         hipLaunchKernelGGL((k_qr_stack_pack<T>), dim3(D + 2), dim3(256), 0, st, (const T *)d_qA.p, q_lda, D, rank, d_qB.p, qb_ld(), qb_nmat(), (const T *)d_gc.p,
                            (const T *)d_scal.p, (int)SC_ELOC);
@@ -620,7 +631,7 @@ template <typename T> struct Solver final : SolverBase {
     void launch_qr_stack_solve()
     {
         hipLaunchKernelGGL((k_qr_stack_unpack<T>), dim3((D + 255) / 256), dim3(256), 0, st, (const T *)d_qB.p, qb_nmat(), D, d_gcg.p, d_scal.p, (int)SC_ENERGY);
-        ba_qr_solve<T>(st, d_qB.p, qb_ld(), world * D, D, d_qtau.p, q_tau_stride, d_dxc.p, st_qr, ev_qr[0], ev_qr[1]);
+        ba_qr_solve<T>(st, d_qB.p, qb_ld(), world * D, D, d_qtau.p, q_tau_stride, d_dxc.p, qr_side());
     }
     // what the exchange step of a sharded trial sums: the packed reduced camera system, or (QRKIT / QRSPQR) the stack of R factors
     T *xchg_ptr() { return dense_qr() ? d_qB.p : d_pack.p; }

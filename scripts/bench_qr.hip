@@ -24,17 +24,23 @@ int main(int argc, char **argv)
         for (int r = 0; r < m; r++) h[(size_t)c * lda + r] = (T)(rand() / (double)RAND_MAX - 0.5) * ((r % 37 == c % 37) ? 8 : 1);
     T *A, *A0, *tau, *y;
     const size_t tstride = (size_t)((m + ba_qr_cfg<T>::CH - 1) / ba_qr_cfg<T>::CH + 2) * BA_QR_PB * BA_QR_PB;
-    CK(hipMalloc(&A, sizeof(T) * h.size())); CK(hipMalloc(&A0, sizeof(T) * h.size())); CK(hipMalloc(&tau, sizeof(T) * 8 * tstride)); CK(hipMalloc(&y, sizeof(T) * (n + 64)));
+    CK(hipMalloc(&A, sizeof(T) * h.size())); CK(hipMalloc(&A0, sizeof(T) * h.size())); CK(hipMalloc(&tau, sizeof(T) * 2 * BA_QR_TAU_LEVELS * tstride)); CK(hipMalloc(&y, sizeof(T) * (n + 64)));
     CK(hipMemcpy(A0, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
-    hipStream_t st, st2; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    hipEvent_t e0, e1, ea, eb; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipEventCreateWithFlags(&ea, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    hipStream_t st, st2, st3; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&st3, hipStreamNonBlocking));
+    hipEvent_t e0, e1, ea, eb, ec; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventCreateWithFlags(&ea, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eb, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+    ba_qr_side sd; // BENCH_QR_STREAMS = 1 | 2 | 3 (default): one stream, trailing updates beside the chain, look-ahead on a third one
+    { const int ns = getenv("BENCH_QR_STREAMS") ? atoi(getenv("BENCH_QR_STREAMS")) : 3;
+      if (ns >= 2) { sd.st2 = st2; sd.ev_chunk = ea; sd.ev_apply = eb; }
+      if (ns >= 3) { sd.st3 = st3; sd.ev_next = ec; }
+      printf("streams: %d\n", ns); }
     float tot = 0;
     const int reps = 5;
     for (int rep = 0; rep <= reps; rep++) {
         CK(hipMemcpyAsync(A, A0, sizeof(T) * h.size(), hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
-        ba_qr_solve<T>(st, A, lda, m, n, tau, tstride, y, st2, ea, eb);
+        ba_qr_solve<T>(st, A, lda, m, n, tau, tstride, y, sd);
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
