@@ -341,10 +341,19 @@ __global__ __launch_bounds__(256) void k_cam_gram_reduce(int N, const int *__res
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int a = idx / BA_SLAB, e = idx - a * BA_SLAB;
     if (a >= N || e >= 54) return;
-    // four interleaved partial sums (fixed order) keep four loads in flight
+    // four interleaved partial sums in a fixed order; sixteen loads are issued before the first of their additions (the additions
+    // and their order are those of a four-at-a-time loop -- the same bits -- but a camera of problem-21 has 54 chunks, and four loads
+    // per L2 round trip made this launch a 14-trip latency chain: 9.1 us)
     T s4[4] = {0, 0, 0, 0};
     const int c0 = cam_dchunk_ptr[a], c1 = cam_dchunk_ptr[a + 1];
     int c = c0;
+    for (; c + 15 < c1; c += 16) {
+        T x[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) x[u] = dslab[(size_t)(c + u) * BA_SLAB + e];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s4[u & 3] += x[u];
+    }
     for (; c + 3 < c1; c += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) s4[u] += dslab[(size_t)(c + u) * BA_SLAB + e];
@@ -857,6 +866,9 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wav
 // same order of additions as k_post_reduce: (V - s) + lambda), row D + 1 is not written at all, and `post_blocks` more workgroups
 // at the end of the grid copy g_c out, clear the rows below the rhs row, give the padding its unit diagonal and arm the backward
 // sweep's vectors.
+// (Eight lanes per output, their partial sums meeting in a butterfly, were measured here and in k_cam_gram_reduce: config 2 7250 ->
+// 7740 LM it/s -- but another order of additions, and at lambda <= 1e-9 (cond 1e19 and worse) that is enough to move single trials
+// of the referee tests across their bounds.  The order of the additions stays; only more of their loads are in flight.)
 template <typename T>
 __global__ __launch_bounds__(192) void k_schur_reduce(int nred, const int *__restrict__ red_pairs, int D, int ld, const int *__restrict__ pair_hi,
                                                       const int *__restrict__ pair_lo, const int *__restrict__ pair_chunk_ptr,
@@ -883,12 +895,19 @@ __global__ __launch_bounds__(192) void k_schur_reduce(int nred, const int *__res
     const int idx = blockIdx.x * 192 + threadIdx.x;
     const int q = idx / BA_SLAB, e = idx - q * BA_SLAB;
     if (q >= nred || e >= 90) return;
-    const int p = red_pairs[q]; // the pairs with no chunk or with several (k_schur_pairs writes the single-chunk ones itself)
+    const int p = red_pairs[q]; // the pairs with no chunk or with several, and every diagonal pair (k_schur_pairs writes the other single-chunk ones itself)
     const int hi = pair_hi[p], lo = pair_lo[p];
     if (e >= 81 && hi != lo) return;
-    T s4[4] = {0, 0, 0, 0}; // four interleaved partial sums (fixed order) keep four loads in flight
+    T s4[4] = {0, 0, 0, 0}; // four interleaved partial sums (fixed order); sixteen loads in flight for the long lists (k_cam_gram_reduce)
     const int c1 = pair_chunk_ptr[p + 1];
     int c = pair_chunk_ptr[p];
+    for (; c + 15 < c1; c += 16) {
+        T x[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) x[u] = slab[(size_t)(c + u) * BA_SLAB + e];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s4[u & 3] += x[u];
+    }
     for (; c + 3 < c1; c += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) s4[u] += slab[(size_t)(c + u) * BA_SLAB + e];

@@ -561,8 +561,8 @@ template <typename T> struct Solver final : SolverBase {
             if (kind == BA_CHOLESKY) BA_PAIRS(true); else BA_PAIRS(false);
 #undef BA_PAIRS
         }
-        const long long nthr = (long long)nred * BA_SLAB;
         const int post_blocks = lamf ? (Dp + 2) / 3 : 0;
+        const long long nthr = (long long)nred * BA_SLAB;
         if (nred > 0)
             hipLaunchKernelGGL((k_schur_reduce<T>), dim3((unsigned)((nthr + 191) / 192) + post_blocks), dim3(192), 0, st, nred, d_red_pairs.p, D, ld,
                                d_pair_hi.p, d_pair_lo.p, d_pair_chunk_ptr.p, d_slab.p, d_V.p, d_gc.p, d_S.p, lamf, post_blocks, Dp, d_gcg.p, d_dxc.p);

@@ -238,6 +238,28 @@ def test_minimize_through_rejections(ba, O, gpu_ok, kind):
     assert relmax(s.get(ba.GET_POINTS), rs["pts"]) < 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 1])
+def test_folded_launches_change_no_bit(ba, gpu_ok, prob21, kind, monkeypatch):
+    """On a single shard k_post_reduce rides on the Schur reduce launch and the trial's three sums on k_lm_control (ba_solver.hip:
+    post_folded / ctl_reduces); BA_NO_FOLD=1 (read at solver creation) gives each its own launch again.  Same additions in the same
+    order either way: the LM table of a run through rejections and acceptances is equal BIT FOR BIT, and so is the final state."""
+    runs = []
+    for no_fold in (False, True):
+        if no_fold:
+            monkeypatch.setenv("BA_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("BA_NO_FOLD", raising=False)
+        s = ba.Solver(prob21, kind, ba.F64)
+        r = s.minimize(max_trials=25)
+        runs.append((r["trace"][:, :5].copy(), s.get(ba.GET_CAMS).copy(), s.get(ba.GET_POINTS).copy(), r["energy"]))
+        del s
+    (ta, ca, pa, ea), (tb, cb, pb, eb) = runs
+    assert ta.shape == tb.shape == (25, 5)
+    assert np.array_equal(ta, tb) and ea == eb
+    assert np.array_equal(ca, cb) and np.array_equal(pa, pb)
+
+
 # ---- stdout protocol of the executables ---------------------------------------------------------------------------
 
 def _numbers_close(a, b, rtol):
