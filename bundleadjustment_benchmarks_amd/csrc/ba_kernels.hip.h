@@ -239,13 +239,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_reduce_scalars(ba
 // ---- K3 (point part): U0_j = sum B^T B, g_p = -sum B^T r per point, once per outer iteration ------------------
 // JtRes and the squared column norms of the point columns (src/Eigen_ext/BacktrackLevMarqQRChol.h:267-274).
 template <typename T>
-__global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
-                                                    const T *__restrict__ r, T *__restrict__ U0, T *__restrict__ gp,
-                                                    T *__restrict__ partial_dmax, const int *__restrict__ go = nullptr)
+__device__ __forceinline__ void ba_point_prep_block(int bid, int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
+                                                    const T *__restrict__ r, T *__restrict__ U0, T *__restrict__ gp, T *__restrict__ partial_dmax)
 {
     __shared__ T red[4];
-    if (go && *go == 0) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = bid * 256 + threadIdx.x;
     T dm = 0;
     if (j < Ml) {
         T U[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -271,7 +269,15 @@ __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__
         dm = tmax(U[0], tmax(U[3], U[5]));
     }
     dm = block_reduce<T, true>(dm, red);
-    if (threadIdx.x == 0) partial_dmax[blockIdx.x] = dm;
+    if (threadIdx.x == 0) partial_dmax[bid] = dm;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp,
+                                                    const T *__restrict__ r, T *__restrict__ U0, T *__restrict__ gp,
+                                                    T *__restrict__ partial_dmax, const int *__restrict__ go = nullptr)
+{
+    if (go && *go == 0) return;
+    ba_point_prep_block<T>(blockIdx.x, Ml, K, pt_ptr, Jp, r, U0, gp, partial_dmax);
 }
 
 // ---- K3 (camera part): V_aa = sum A^T A (9x9) and g_c = -sum A^T r per camera, once per outer iteration -------
@@ -281,13 +287,11 @@ __global__ __launch_bounds__(256) void k_point_prep(int Ml, int K, const int *__
 // lane order -> deterministic).  A lane-per-output mapping walked the 32 observations one after the other and was
 // latency-bound (85 us for 226 k observations).
 template <typename T>
-__global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
-                                                  const int *__restrict__ cam_obs, const T *__restrict__ JcA,
-                                                  T *__restrict__ dslab, const int *__restrict__ go = nullptr)
+__device__ __forceinline__ void ba_cam_gram_block(int bid, int ndchunks, int K, const int *__restrict__ dchunk_ptr, const int *__restrict__ cam_obs,
+                                                  const T *__restrict__ JcA, T *__restrict__ dslab)
 {
     __shared__ T xch[8][27][33];
-    if (go && *go == 0) return;
-    const int gl = threadIdx.x >> 5, g = blockIdx.x * 8 + gl, sub = threadIdx.x & 31;
+    const int gl = threadIdx.x >> 5, g = bid * 8 + gl, sub = threadIdx.x & 31;
     const bool gok = g < ndchunks;
     const int e0 = gok ? dchunk_ptr[g] : 0, len = gok ? dchunk_ptr[g + 1] - e0 : 0;
     T v[54];
@@ -320,6 +324,28 @@ __global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int
             dslab[(size_t)g * BA_SLAB + 27 * pass + sub] = a;
         }
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_cam_gram(int ndchunks, int K, const int *__restrict__ dchunk_ptr,
+                                                  const int *__restrict__ cam_obs, const T *__restrict__ JcA,
+                                                  T *__restrict__ dslab, const int *__restrict__ go = nullptr)
+{
+    if (go && *go == 0) return;
+    ba_cam_gram_block<T>(blockIdx.x, ndchunks, K, dchunk_ptr, cam_obs, JcA, dslab);
+}
+// Both in ONE launch (the first gM workgroups take the points, the rest the cameras' chunks): the two are independent, and for a
+// problem whose point part is a single round of workgroups (config 4: 255) neither fills the chip by itself -- 10.6 + 13.4 us as two
+// launches.  (Every workgroup reserves the camera part's 57 KB of LDS, so a larger point part would lose its occupancy: the host
+// keeps the two launches there.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_grad_prep(int gM, int Ml, int K, const int *__restrict__ pt_ptr, const T *__restrict__ Jp, const T *__restrict__ r,
+                                                   T *__restrict__ U0, T *__restrict__ gp, T *__restrict__ partial_dmax, int ndchunks,
+                                                   const int *__restrict__ dchunk_ptr, const int *__restrict__ cam_obs, const T *__restrict__ JcA,
+                                                   T *__restrict__ dslab, const int *__restrict__ go = nullptr)
+{
+    if (go && *go == 0) return;
+    if ((int)blockIdx.x < gM) ba_point_prep_block<T>(blockIdx.x, Ml, K, pt_ptr, Jp, r, U0, gp, partial_dmax); // (uniform per workgroup)
+    else ba_cam_gram_block<T>(blockIdx.x - gM, ndchunks, K, dchunk_ptr, cam_obs, JcA, dslab);
 }
 
 // tail.src != nullptr: one more block at the end of the grid sums the energy partials of k_eval (the reduction that closes a

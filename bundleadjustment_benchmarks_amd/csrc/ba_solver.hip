@@ -454,10 +454,15 @@ template <typename T> struct Solver final : SolverBase {
     // tail: the energy reduction that closes the linearisation, as one more block of the last launch (+ the control segment's end stamp)
     void launch_grad(const int *go = nullptr, const ba_red_job *tail = nullptr)
     {
-        hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p, d_part_pm.p, go);
-        if (sx.ndchunks > 0)
-            hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
-                               d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
+        if (sx.ndchunks > 0 && gM <= 2 * num_cus && !no_fold) // a point part of one round of workgroups: both in one launch (k_grad_prep)
+            hipLaunchKernelGGL((k_grad_prep<T>), dim3(gM + (sx.ndchunks + 7) / 8), dim3(256), 0, st, gM, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p,
+                               d_part_pm.p, sx.ndchunks, d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
+        else {
+            hipLaunchKernelGGL((k_point_prep<T>), dim3(gM), dim3(256), 0, st, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p, d_part_pm.p, go);
+            if (sx.ndchunks > 0)
+                hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
+                                   d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
+        }
         hipLaunchKernelGGL((k_cam_gram_reduce<T>), dim3((N * BA_SLAB + 255) / 256 + (tail ? 1 : 0)), dim3(256), 0, st, N, d_cam_dchunk_ptr.p,
                            d_dslab.p, d_V.p, d_gc.p, go, tail ? *tail : ba_red_job{nullptr, 0, 0, 0}, d_scal.p, tail ? &d_lm.p->t_end : (long long *)nullptr);
     }
