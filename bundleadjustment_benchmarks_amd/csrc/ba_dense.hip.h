@@ -1056,9 +1056,9 @@ __global__ __launch_bounds__(256) void k_ldlt_backpair(int ncols, int ld, int zr
 // appear -- each x(i) is an 8-byte granule that its owner publishes with an agent-scope (write-through) store over a
 // sentinel, so a consumer polls the very datum it needs and no flag or ordering is involved -- with the 128 x 128 block of
 // L for the next group already in registers; then it solves its own group like k_ldlt_backpair and publishes.  The chain is
-// one hop per group: poll, 64 FMAs per thread, three LDS GEMV phases.  All groups must be resident at once (19 workgroups
-// at config 4, 72 at config 5; the spins are bounded anyway).  x must hold the sentinel on entry (k_post_reduce /
-// k_fill_sentinel).
+// one hop per group: poll, 64 FMAs per thread, three LDS GEMV phases.  A group only waits for groups dispatched BEFORE it (the last
+// group has the lowest workgroup index), so the launch makes progress whether or not all of it is resident (38 workgroups at
+// config 4, 144 at config 5; the spins are bounded anyway).  x must hold the sentinel on entry (k_post_reduce / k_fill_sentinel).
 template <typename T>
 __global__ void k_fill_sentinel(int n, T *__restrict__ x)
 {
@@ -1186,8 +1186,9 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 // Host side of the backward sweep on `st`.  armed: x already holds the sentinel (the solver's k_post_reduce does that).
 template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x);
 
-// max_groups: how many workgroups of k_ldlt_backflow are certainly resident at once (one per CU is a safe count; they
-// wait for each other, so a grid beyond that -- two workgroups per group -- falls back to a launch per pair of block columns).
+// max_groups: beyond that many workgroups (two per group) the sweep falls back to a launch per pair of block columns.  (No longer a
+// residency requirement -- k_ldlt_backflow's waits all point at earlier-dispatched workgroups -- but a chain longer than the chip
+// is wide has nothing to gain from one launch.)
 // zh: room for 128 scalars per group (the helpers' partial sums), armed with the sentinel like x.
 template <typename T, int NB>
 inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, T *zh, bool armed = false, int max_groups = 256,
