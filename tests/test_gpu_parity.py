@@ -395,6 +395,28 @@ def test_dense_block_widths(ba, O, gpu_ok, ncams):
         assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
 
 
+def test_schur_assembly_does_not_depend_on_the_dealing(ba, gpu_ok, prob21, monkeypatch):
+    """k_schur_pairs is a persistent grid: which wavefront takes which chunk of a camera pair is decided on the host (workgroups per
+    CU, XCD bands, windows of the pair list -- BA_SCHUR_WGS / _BANDS / _WINDOW, read at solver creation; config 5 runs with 2 / 8 / 1,
+    the small configs with 4 / 8 / 0).  A chunk's sum and the order of a pair's chunks do not depend on that, so S, the reduced
+    right-hand side and the step are the same BITS under every dealing."""
+    ref = None
+    for wgs, bands, window in ((4, 8, 0), (2, 8, 1), (1, 1, 0), (3, 8, 4), (4, 1, 2)):
+        monkeypatch.setenv("BA_SCHUR_WGS", str(wgs))
+        monkeypatch.setenv("BA_SCHUR_BANDS", str(bands))
+        monkeypatch.setenv("BA_SCHUR_WINDOW", str(window))
+        s = ba.Solver(prob21, ba.CHOLESKY, ba.F64)
+        s.keep_intermediates(True)
+        s.linearize()
+        out = s.try_step(3e-4)
+        got = (s.get(ba.GET_S).copy(), s.get(ba.GET_DX).copy(), out)
+        del s
+        if ref is None:
+            ref = got
+        else:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2], (wgs, bands, window)
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
     """Per-point QR with tracks of 40 / 100 / 200 / 300 / 700 observations (one bucket of lanes-per-point each, the last
