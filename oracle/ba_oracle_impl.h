@@ -584,10 +584,59 @@ static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) 
  * QRCHOL: S = J2bot^T J2bot, rhs = -J2bot^T qtb2 (BacktrackLevMarqQRChol.h:334-341), evaluated as
  * (A^T A + lambda I) - R12^T R12 and g_c + R12^T q1 -- algebraically identical because Q is orthogonal.
  * CHOLESKY: the Schur complement of the point block of J^T J + lambda I. */
+#ifndef ORA_WIDE_SUMS_DECLARED
+#define ORA_WIDE_SUMS_DECLARED
+/* Experiment switch (default 0 = the oracle as committed): the long sums of the reduced camera system -- S, its rhs and g_c, thousands
+ * of terms per entry, which this restatement (like a sparse product) adds one after the other -- are accumulated in long double and
+ * rounded once.  Nothing else changes.  Used by tests/golden/make_referee.py (ensemble_*_widesums) to show which part of the fp64
+ * oracle's rounding noise decides where its free run stops. */
+static int ora_wide_sums_flag = 0;
+void ora_set_wide_sums(int on) { ora_wide_sums_flag = on; }
+#endif
 static void FN(build_reduced)(int N, int K, const int *cam_idx, const int *pt_idx, const int *pt_ptr, int M,
                               const S *Jc, const S *fvec, S lambda, const FN(elim_t) * e, S *Smat, S *rhs, S *gc)
 {
     const int D = 9 * N;
+    if (ora_wide_sums_flag) {
+        long double *W = (long double *)calloc((size_t)D * D + 2 * (size_t)D, sizeof(long double));
+        long double *wr = W + (size_t)D * D, *wg = wr + D;
+        for (int i = 0; i < K; i++) {
+            const S *A = Jc + 18 * (size_t)i;
+            const S *r = fvec + 2 * (size_t)i;
+            const int a = cam_idx[i];
+            for (int c = 0; c < 9; c++) wg[9 * a + c] -= A[c] * r[0] + A[9 + c] * r[1];
+            for (int c = 0; c < 9; c++)
+                for (int c2 = 0; c2 < 9; c2++) W[(size_t)(9 * a + c2) * D + 9 * a + c] += A[c] * A[c2] + A[9 + c] * A[9 + c2];
+        }
+        for (int j = 0; j < M; j++) {
+            const S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j;
+            const S td[3] = {dinv[0] * t[0], dinv[1] * t[1], dinv[2] * t[2]};
+            for (int ia = pt_ptr[j]; ia < pt_ptr[j + 1]; ia++) {
+                const S *Za = e->Z + 27 * (size_t)ia;
+                const int a = cam_idx[ia];
+                for (int c = 0; c < 9; c++) wr[9 * a + c] -= Za[3 * c] * td[0] + Za[3 * c + 1] * td[1] + Za[3 * c + 2] * td[2];
+                for (int ib = pt_ptr[j]; ib < pt_ptr[j + 1]; ib++) {
+                    const S *Zb = e->Z + 27 * (size_t)ib;
+                    const int b = cam_idx[ib];
+                    for (int c = 0; c < 9; c++) {
+                        const S z0 = Za[3 * c] * dinv[0], z1 = Za[3 * c + 1] * dinv[1], z2 = Za[3 * c + 2] * dinv[2];
+                        for (int c2 = 0; c2 < 9; c2++)
+                            W[(size_t)(9 * b + c2) * D + 9 * a + c] -= z0 * Zb[3 * c2] + z1 * Zb[3 * c2 + 1] + z2 * Zb[3 * c2 + 2];
+                    }
+                }
+            }
+        }
+        for (int c = 0; c < D; c++) {
+            W[(size_t)c * D + c] += lambda;
+            wr[c] += wg[c];
+        }
+        for (size_t q = 0; q < (size_t)D * D; q++) Smat[q] = (S)W[q];
+        for (int c = 0; c < D; c++) { rhs[c] = (S)wr[c]; gc[c] = (S)wg[c]; }
+        free(W);
+        (void)pt_idx;
+        return;
+    }
+
     memset(Smat, 0, sizeof(S) * (size_t)D * D);
     for (int c = 0; c < D; c++) { rhs[c] = 0; gc[c] = 0; }
     for (int i = 0; i < K; i++) {

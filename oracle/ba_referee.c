@@ -220,3 +220,38 @@ int ref_minimize(int kind, int N, int M, int K, const int *cam_idx, const int *p
     free(c); free(p); free(ms);
     return status;
 }
+
+/* ---- the oracle a fourth time: S = long double (x87 extended: 64-bit significand, eps 1.1e-19 = fp64's / 2048) -----------------------
+ * Round 4: a free run in this arithmetic costs ~3x an fp64 one (a __float128 run: ~1000x), so WHOLE ENSEMBLES of free runs are affordable.
+ * They answer what single quad runs cannot: does the DISTRIBUTION of final energies of the reference algorithm depend on the size of the
+ * rounding noise of its linear solves?  (tests/golden/make_referee.py: ensemble_*_x87) */
+#undef S
+#undef FN
+#undef SQRT
+#undef FABS
+#undef SIN
+#undef COS
+#undef POW
+#define S long double
+#define FN(name) CAT(name, _f80)
+#define SQRT sqrtl
+#define FABS fabsl
+#define SIN sinl
+#define COS cosl
+#define POW powl
+#include "ba_oracle_impl.h"
+
+int ref80_minimize(int kind, int N, int M, int K, const int *cam_idx, const int *pt_idx, const double *meas, double tau, double *cam15,
+                   double *pts, const double *lm, int max_iter, int max_fun_ev, int max_trials, double *trace, int *ntrials_out)
+{
+    S *c = (S *)malloc(sizeof(S) * 15 * (size_t)N), *p = (S *)malloc(sizeof(S) * 3 * (size_t)M), *ms = (S *)malloc(sizeof(S) * 2 * (size_t)K);
+    if (!c || !p || !ms) return -4;
+    for (size_t i = 0; i < 15 * (size_t)N; i++) c[i] = cam15[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) p[i] = pts[i];
+    for (size_t i = 0; i < 2 * (size_t)K; i++) ms[i] = meas[i];
+    const int status = ora_minimize_f80(kind, N, M, K, cam_idx, pt_idx, ms, (S)tau, c, p, lm, max_iter, max_fun_ev, max_trials, trace, ntrials_out, NULL);
+    for (size_t i = 0; i < 15 * (size_t)N; i++) cam15[i] = (double)c[i];
+    for (size_t i = 0; i < 3 * (size_t)M; i++) pts[i] = (double)p[i];
+    free(c); free(p); free(ms);
+    return status;
+}

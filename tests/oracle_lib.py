@@ -42,6 +42,11 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def set_wide_sums(on):
+    """Experiment switch of oracle/ba_oracle_impl.h (build_reduced): S, rhs and g_c accumulated in long double.  Default off."""
+    lib().ora_set_wide_sums(int(bool(on)))
+
+
 def set_threads(n):
     """OpenMP threads of the dense factorisation (results do not depend on it)."""
     lib().ora_set_threads(int(n))
@@ -67,6 +72,17 @@ class Problem:
         k = int(np.searchsorted(self.pt_idx, n_points, side="left"))
         return Problem(self.N, n_points, k, self.cam_idx[:k], self.pt_idx[:k], self.meas[: 2 * k], self.cams9,
                        self.pts[: 3 * n_points])
+
+
+def ensemble_member(p, k, rel=1e-13):
+    """Member k of the 1e-13 ensembles (tests/golden/make_referee.py, tests/test_gpu_configs.py): the problem with cameras and points
+    perturbed by rel x N(0,1) relative, seeded 1000 + k; member 0 is the unperturbed input.  The SAME inputs go to the oracle and the GPU."""
+    if k == 0:
+        return p
+    rng = np.random.default_rng(1000 + k)
+    cams9 = p.cams9 * (1 + rel * rng.standard_normal(p.cams9.shape))
+    pts = p.pts * (1 + rel * rng.standard_normal(p.pts.shape))
+    return Problem(p.N, p.M, p.K, p.cam_idx, p.pt_idx, p.meas, cams9, pts)
 
 
 def load_bal(path):
@@ -217,14 +233,15 @@ def referee_trial(kind, p, cam15, pts, lam, tau=0.5, want_dx=False):
     return r
 
 
-def referee_minimize(kind, p, max_trials=100000, lm=LM_DEFAULTS, max_iter=1000000, max_fun_ev=1000000, tau=0.5):
-    """The LM loop in quad precision from the problem's double start (oracle/ba_referee.c: ref_minimize) -- minutes for problem-21."""
+def referee_minimize(kind, p, max_trials=100000, lm=LM_DEFAULTS, max_iter=1000000, max_fun_ev=1000000, tau=0.5, x87=False):
+    """The LM loop in quad precision from the problem's double start (oracle/ba_referee.c: ref_minimize) -- minutes for problem-21;
+    x87: in long double instead (ref80_minimize: eps 1.1e-19, ~3x an fp64 run)."""
     cam15 = init_cams(p)
     pts = p.pts.copy()
     trace = np.zeros((max_trials, 8))
     lmv = np.asarray(lm, np.float64)
     ntr = C.c_int(0)
-    status = referee().ref_minimize(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
+    status = (referee().ref80_minimize if x87 else referee().ref_minimize)(kind, p.N, p.M, p.K, _p(p.cam_idx), _p(p.pt_idx), _p(p.meas), C.c_double(tau), _p(cam15), _p(pts),
                                     _p(lmv), max_iter, max_fun_ev, max_trials, _p(trace), C.byref(ntr))
     return dict(status=status, trace=trace[: ntr.value], cam15=cam15, pts=pts)
 

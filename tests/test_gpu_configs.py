@@ -315,24 +315,49 @@ def test_executable_stdout_protocol(ba, O, gpu_ok):
             assert _numbers_close(a, b, 1e-3 if (row and q >= 2) or after else 2e-6), (got, want)
 
 
-@pytest.mark.parametrize("kind_name", ["qrchol", "cholesky"])
-def test_final_energy_within_the_reference_algorithms_own_spread(ba, gpu_ok, prob21, kind_name):
+@pytest.mark.parametrize("case", ["problem21_qrchol", "problem21_cholesky", "cfg1_cholesky"])
+def test_final_energy_distribution_matches_the_reference_algorithms(ba, O, gpu_ok, case):
     """north_star asks for the reference's final cost to 1e-6.  On these inputs that number does not exist at 1e-6 for the reference
     algorithm itself: its free run amplifies rounding by ~10x per iteration, and from inputs perturbed by 1e-13 (relative) the fp64 oracle
-    stops -- same flat-line test -- anywhere in a band of +-0.5 ... 1 % (tests/golden/referee_ensemble_problem21_*.json: 16 runs each,
-    96 ... 347 trials; even the two QUAD-precision free runs, QRCHOL and CHOLESKY, end 4.5e-4 apart: referee_freerun_*.json).  What can
-    be asserted, and is: the GPU's free run to the reference's own stop ends with status Success inside that band -- within the
-    ensemble's range widened by half its width (16 members do not pin the extremes of the distribution)."""
+    stops -- same flat-line test -- anywhere in a band of ~ +-1 % (tests/golden/referee_ensemble_*.json: 64 runs each; even the two
+    QUAD-precision free runs, QRCHOL and CHOLESKY, end 4.5e-4 apart: referee_freerun_*.json).  One GPU run against that band cannot
+    tell a chance draw from a systematic early stop, so the comparison is between DISTRIBUTIONS: the same 64
+    perturbed inputs go through ba_minimize.
+
+    What round 4 found (profiles/r04_final_cost_ensembles.json): the GPU's distribution is NOT the plain fp64
+    oracle's -- its median final energy is higher by ~0.4 % (Mann-Whitney p = 1e-13 on problem-21 QRCHOL) at the same number of trials.
+    The cause is in the ORACLE: it adds the thousands of terms of every entry of the reduced camera system one after the other, and
+    that summation noise, amplified by cond ~ 1e20 at the lambda floor, kicks its free run along the gauge directions (|points| drifts
+    by 10 % against the GPU's 1 %) and into lower basins of the robust cost.  The same oracle with ONLY those sums accumulated in long
+    double (..._widesums.json), or run entirely in x87 long double (..._x87.json), has the GPU's distribution.  So:
+      * every run on either side ends with status Success;
+      * the GPU's median final energy and median trial count lie inside the plain fp64 ensemble's [min, max] -- no widening;
+      * against the accurately-summed fp64 oracle the two-sample rank test (Mann-Whitney, two-sided) does not tell the GPU apart:
+        p > 0.01 on final energy AND on trial count."""
+    import ensemble_lib as E
+    n = 64
+    gpu = E.gpu_members(ba, O, case, n)
+    plain = E.compare(E.fixture(case), gpu)
+    wide = E.compare(E.fixture(case + "_widesums"), gpu)
+    print("\n%s vs the fp64 oracle as it is: %s\n%s vs the fp64 oracle with accurately summed S: %s" % (case, plain, case, wide))
+    assert plain["gpu_all_success"] and plain["oracle_all_success"] and wide["oracle_all_success"], (plain, wide)
+    assert plain["oracle_energy_min"] <= plain["gpu_energy_median"] <= plain["oracle_energy_max"], plain
+    assert plain["oracle_trials_min"] <= plain["gpu_trials_median"] <= plain["oracle_trials_max"], plain
+    assert wide["p_energy"] > 0.01 and wide["p_trials"] > 0.01, wide
+
+
+@pytest.mark.parametrize("kind_name", ["qrchol", "cholesky"])
+def test_free_run_prefix_matches_the_quad_free_run(ba, gpu_ok, prob21, kind_name):
+    """The tight, deterministic pin beside the ensembles: while the trajectories have not yet bifurcated -- the first eight
+    table rows on problem-21 -- the GPU's free run IS the quad-precision free run of the reference algorithm
+    (tests/golden/referee_freerun_problem21_*.json, oracle/ba_referee.c in __float128): same accept decisions, energies to 1e-6
+    relative (measured: 5e-16 ... 1.3e-7 QRCHOL, ... 6.0e-7 CHOLESKY, whose row 8 is at 1.03e-6; the fp64 oracle itself is at 4e-5 by row 7), lambda to 1e-5."""
     import json
-    import os
-    from conftest import ROOT
-    ens = json.load(open(os.path.join(ROOT, "tests", "golden", "referee_ensemble_problem21_%s.json" % kind_name)))
+    q = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "referee_freerun_problem21_%s.json" % kind_name)))["trace"])
     kind = {"qrchol": ba.QRCHOL, "cholesky": ba.CHOLESKY}[kind_name]
-    r = ba.Solver(prob21, kind, ba.F64).minimize()
-    lo, hi = ens["final_energy_min"], ens["final_energy_max"]
-    tmin, tmax = min(m["trials"] for m in ens["members"]), max(m["trials"] for m in ens["members"])
-    print("\nproblem-21 %s: GPU final energy %.6f after %d trials (status %s); oracle ensemble %.3f .. %.3f (median %.3f), %d .. %d trials" %
-          (kind_name, r["energy"], r["trials"], ba.STATUS[r["status"]], lo, hi, ens["final_energy_median"], tmin, tmax))
-    assert r["status"] == 0 and all(m["status"] == 0 for m in ens["members"])
-    assert lo - 0.5 * (hi - lo) <= r["energy"] <= hi + 0.5 * (hi - lo), (r["energy"], lo, hi)
-    assert tmin // 2 <= r["trials"] <= 2 * tmax
+    g = ba.Solver(prob21, kind, ba.F64).minimize(max_trials=8)["trace"]
+    rel = np.abs(g[:8, 2] - q[:8, 2]) / q[:8, 2]
+    print("\n%s: |f_gpu - f_quad| / f_quad over the first eight rows: %s" % (kind_name, " ".join("%.1e" % v for v in rel)))
+    assert np.array_equal(g[:8, :2], q[:8, :2])
+    assert rel.max() <= 1e-6, rel
+    assert np.allclose(g[:8, 4], q[:8, 4], rtol=1e-5, atol=0)
