@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- LM iterations/sec of the MI355X bundle-adjustment solver on the BASELINE.json workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N rank processes, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+The timed region -- exactly K trials between two barrier + synchronize pairs -- is run R = --regions (7) times, every time from the
+restored initial parameters; `ms_per_step` / `value` are the MEDIAN region's, min / max beside them (`steps` stays the per-region count).
 
 A "step" is one Levenberg-Marquardt trial = one row of the reference's iteration table
 (src/Eigen_ext/BacktrackLevMarqCholesky.h:308,322): point elimination, Schur assembly, dense LDL^T + solve,
@@ -57,24 +60,44 @@ def algorithmic_bytes(N, M, K, S=8):
     return b_evalRJ, b_evalR, b_schur
 
 
-def pmc_traffic(workload, kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r03_pmc_<workload>.json: rocprofv3 --pmc FETCH_SIZE /
+def kernel_source_sha16():
+    """sha256 over the HIP / C++ sources of the library: a PMC pass describes the kernels of ONE source state."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bundleadjustment_benchmarks_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp", ".c")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_ROUND = "r04"
+
+
+def pmc_traffic(workload, kernel_name):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/<round>_pmc_<workload>.json: rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in passes of their own -- they cannot ride on this run --, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950; profiles/r03_fetch_size_control.txt shows the doubling holds for this repo's gathers too).  None when the file is absent."""
+    gfx950; profiles/r03_fetch_size_control.txt shows the doubling holds for this repo's gathers too).  None when the file is absent,
+    when it was collected from OTHER kernel sources than the ones this run uses (its `source_sha16`), or when it has no entry of
+    exactly this kernel name (template arguments behind the name are ignored: 'k_ldlt_step' does not match 'k_ldlt_step2')."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)))[workload]
+        doc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PMC_ROUND, workload))))
+        d = doc[workload]
     except Exception:
         return None
+    if doc.get("source_sha16") != kernel_source_sha16():
+        return None
     for k, v in d.items():
-        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch_fetch_x2" in v:
+        if k.split("<")[0] == kernel_name and "hbm_bytes_per_launch_fetch_x2" in v:
             return {"bytes_per_launch": v["hbm_bytes_per_launch_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_per_launch_raw"],
-                    "source": "profiles/r03_pmc_%s.json (%s, FETCH_SIZE x 2 + WRITE_SIZE)" % (workload, k)}
+                    "source": "profiles/%s_pmc_%s.json (%s, FETCH_SIZE x 2 + WRITE_SIZE; sources %s)" % (PMC_ROUND, workload, k, doc["source_sha16"])}
     return None
 
 
-def with_traffic(roof, workload, kernel_prefix):
-    """roofline.traffic = HBM bytes per launch (a number, or null without a committed PMC pass); where it comes from beside it."""
-    t = pmc_traffic(workload, kernel_prefix)
+def with_traffic(roof, workload, kernel_name):
+    """roofline.traffic = HBM bytes per launch (a number, or null without a committed PMC pass of these sources); where it comes from beside it."""
+    t = pmc_traffic(workload, kernel_name)
     roof["traffic"] = t["bytes_per_launch"] if t else None
     if t:
         roof["traffic_detail"] = t
@@ -133,33 +156,107 @@ def cpu_baseline(name, prob, budget_s=20.0):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plain: N fresh rank processes, one per GPU, started BEFORE this process makes any GPU call
+    (it never makes one: it only waits).  Rendezvous over 127.0.0.1 (MASTER_ADDR / MASTER_PORT, a free port of this host); rank 0
+    prints the JSON line on this process' stdout.  If any rank fails, the others are stopped, the failing rank's stderr is shown and
+    the exit code is non-zero.  A rank that does not meet the others within BA_BENCH_RENDEZVOUS_S (default 300) seconds counts as failed
+    (torch.distributed's own time-out)."""
+    import subprocess
+    import tempfile
+    n = args.gpus
+    port = free_port()
+    tmp = tempfile.mkdtemp(prefix="ba_bench_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", BA_BENCH_CHILD="1")
+        err = open(os.path.join(tmp, "rank%d.err" % r), "w+")
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                       stdout=None if r == 0 else subprocess.DEVNULL, stderr=err), err))
+    failed = None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            rc = procs[r][0].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in alive:  # the exact processes this function started
+            procs[r][0].terminate()
+        for r in alive:
+            try:
+                procs[r][0].wait(timeout=20)
+            except Exception:
+                procs[r][0].kill()
+        r, rc = failed
+        procs[r][1].seek(0)
+        sys.stderr.write("bench.py: rank %d of %d exited with code %d; its stderr:\n%s\n" % (r, n, rc, procs[r][1].read()[-4000:]))
+        raise SystemExit(1)
+    procs[0][1].seek(0)
+    sys.stderr.write(procs[0][1].read())
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--regions", type=int, default=7, help="timed regions of --steps trials each (median reported)")
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="no GPU: start the ranks, let them meet (gloo), print who met -- the launch path of --gpus N without the solver")
     args = ap.parse_args()
-
-    import torch
-    import bundleadjustment_benchmarks_amd as ba
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)  # (does not return)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="gloo")  # control plane only: id exchange, barriers, max of the timings
+        # control plane only: id exchange, barriers, max of the timings
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("BA_BENCH_RENDEZVOUS_S", "300"))))
+    if args.dry_launch:
+        met = [None] * world
+        if world > 1:
+            dist.all_gather_object(met, (rank, os.getpid()))
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            met = [(rank, os.getpid())]
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_met": [m[0] for m in met], "distinct_processes": len({m[1] for m in met})}))
+        return
+
+    import torch
+    import bundleadjustment_benchmarks_amd as ba
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
 
     kind_s, scalar_s, _, _, _ = WORKLOADS[args.workload]
     kind = {"QRKIT": ba.QRKIT, "QRCHOL": ba.QRCHOL, "CHOLESKY": ba.CHOLESKY}[kind_s]
@@ -182,19 +279,26 @@ def main():
     # warmup: W untimed trials, then restore the initial parameters (inputs stay resident in HBM)
     if args.warmup > 0:
         solver.minimize(max_trials=args.warmup, trace=False)
-    solver.set_state(cam0.reshape(prob.N, 15), pts0)
-    solver.timing(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    res = solver.minimize(max_trials=args.steps, trace=False)
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    regions = []
+    for _ in range(max(args.regions, 1)):  # every region: exactly K trials from the restored start, barrier + synchronize on both sides
+        solver.set_state(cam0.reshape(prob.N, 15), pts0)
+        solver.timing(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        res = solver.minimize(max_trials=args.steps, trace=False)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        tmr = solver.timing()
+        regions.append((el / max(res["trials"], 1), el, res, tmr))
+    order = sorted(range(len(regions)), key=lambda q: regions[q][0])
+    _, el, res, tm = regions[order[len(order) // 2]]  # the median region (all regions replay the same trials: same res)
     steps_done = res["trials"]
-    tm = solver.timing()
+    ms_all = [1e3 * w[0] for w in regions]
+    dev_all = [w[3]["trial_ms"] / max(w[3]["n_trials"], 1) for w in regions]
 
     out = None
     if rank == 0:
@@ -207,6 +311,8 @@ def main():
         out = {
             "metric": "LM iterations/sec", "value": steps_done / el, "unit": "LM iterations/s", "n_gpus": world,
             "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps_done, 1),
+            "regions": len(regions), "ms_per_step_min": min(ms_all), "ms_per_step_max": max(ms_all),
+            "trial_device_ms_min": min(dev_all), "trial_device_ms_max": max(dev_all),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,  # one fixed problem, its points sharded over the ranks
             "dtype": scalar_s, "data": "synthetic" if source.startswith("synthetic") else source,
             "config": {"workload": "%s, BAL problem-%d-%d (K=%d) %s, %s" % (label, N, M, K, source, scalar_s),
@@ -249,7 +355,7 @@ def main():
                                "peak = the fp%d matrix/vector rate)" % ("double" if S == 8 else "float", mrows, D, 8 * S),
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "algorithmic_flops_per_trial": flops_qr, "ms_per_trial": ph["dense_factor"], "secondary": secondary}
-            with_traffic(out["roofline"], args.workload, "k_qr_apply<float, 32" if S == 4 else "k_qr_apply<double, 16")
+            with_traffic(out["roofline"], args.workload, "k_qr_apply")
         elif ph["dense_factor"] >= t_hbm:
             # k_ldlt_step (fused panel + trailing update; k_ldlt_panel for the first block column): nblk launches per trial,
             # each processing 1/nblk of the D^3/3 flops on average
@@ -262,7 +368,7 @@ def main():
                                "launches_per_trial": nblk, "avg_launch_us": 1e3 * ph["dense_factor"] / nblk,
                                "algorithmic_flops_per_launch": flops_factor / nblk, "ms_per_trial": ph["dense_factor"],
                                "secondary": secondary}
-            with_traffic(out["roofline"], args.workload, "k_ldlt_step")
+            with_traffic(out["roofline"], args.workload, "k_ldlt_step2" if D >= 3072 else "k_ldlt_step")
         else:
             out["roofline"] = secondary
         out["phase_replay_ms"] = ph

@@ -108,13 +108,17 @@ int ba_comm_unique_id(void *id_out)
 }
 
 // Rendezvous through a file for processes started by hand (the executables with BA_WORLD / BA_RANK): rank 0 creates the id and
-// publishes it with an atomic rename, the others wait for the file (60 s).  File = the 128-byte id + an 8-byte launch nonce (a hash
-// of the environment variable BA_COMM_NONCE; 0 when unset).
+// publishes it with an atomic rename, the others wait for the file (BA_COMM_WAIT_S seconds, default 60).  File = the 128-byte id +
+// an 8-byte launch nonce (a hash of the environment variable BA_COMM_NONCE; 0 when unset).
 // A file left behind by an earlier run must never be taken for this run's: rank 0 removes whatever is there before it creates the
 // id and removes its own file again once the communicator stands (ba_comm_id_file_done: ncclCommInitRank is collective, every rank
 // has read the id by then), so a stale file only survives a run that died in between.  A reader refuses a file whose nonce is not
-// its own and -- without a nonce -- one that was written more than two seconds before the reader itself started; it keeps
-// polling until rank 0 has replaced it.  The temporary file is created with O_CREAT | O_EXCL | O_NOFOLLOW, mode 0600.
+// its own.  Without a nonce it takes a file that was written after THIS PROCESS started (less two seconds; the start = the moment
+// the library was loaded -- not the moment of this call, which comes after the problem has been loaded and the solver created,
+// seconds later on a big shard: ADVICE r3) at once; an older file -- rank 0 started earlier by hand, or a dead run's leftover --
+// only after it has stayed unchanged for BA_COMM_GRACE_S (default 5) seconds of polling, since this launch's rank 0 would have
+// removed a leftover at its own start.  What remains: a leftover AND a rank 0 that starts more than the grace period after a
+// reader -- set BA_COMM_NONCE per launch to rule that out (INTEGRATION.md does).  Temporary file: O_CREAT | O_EXCL | O_NOFOLLOW, 0600.
 static unsigned long long ba_comm_nonce()
 {
     const char *e = getenv("BA_COMM_NONCE");
@@ -122,6 +126,21 @@ static unsigned long long ba_comm_nonce()
     unsigned long long h = 1469598103934665603ull; // FNV-1a
     for (; *e; e++) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
     return h ? h : 1;
+}
+
+static struct timespec ba_now_realtime()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_REALTIME, &t);
+    return t;
+}
+static const struct timespec g_process_start = ba_now_realtime(); // (static initialiser: runs when the library is loaded)
+
+static double env_seconds(const char *name, double dflt)
+{
+    const char *e = getenv(name);
+    const double v = e && *e ? atof(e) : dflt;
+    return v > 0 ? v : dflt;
 }
 
 int ba_comm_id_via_file(const char *path, int rank, void *id_out)
@@ -144,28 +163,51 @@ int ba_comm_id_via_file(const char *path, int rank, void *id_out)
         if (!ok || rename(tmp.c_str(), path) != 0) { (void)unlink(tmp.c_str()); return BA_ERR_FILE; }
         return BA_OK;
     }
-    struct timespec t0;
-    clock_gettime(CLOCK_REALTIME, &t0);
-    for (int tries = 0; tries < 600; tries++) {
+    const double wait_s = env_seconds("BA_COMM_WAIT_S", 60.0), grace_s = env_seconds("BA_COMM_GRACE_S", 5.0);
+    const struct timespec t0 = g_process_start;
+    const auto begin = std::chrono::steady_clock::now();
+    unsigned char seen[BA_COMM_ID_BYTES + 8];
+    struct timespec seen_mtime = {0, 0};
+    auto seen_since = begin;
+    bool have_seen = false;
+    for (;;) {
+        const auto now = std::chrono::steady_clock::now();
         const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        bool got = false;
+        unsigned char buf[BA_COMM_ID_BYTES + 8];
+        struct stat sb;
         if (fd >= 0) {
-            unsigned char buf[BA_COMM_ID_BYTES + 8];
-            struct stat sb;
-            const bool got = fstat(fd, &sb) == 0 && read(fd, buf, sizeof buf) == (ssize_t)sizeof buf;
+            got = fstat(fd, &sb) == 0 && read(fd, buf, sizeof buf) == (ssize_t)sizeof buf;
             (void)close(fd);
-            if (got) {
-                unsigned long long fn = 0;
-                memcpy(&fn, buf + BA_COMM_ID_BYTES, 8);
+        }
+        if (got) {
+            unsigned long long fn = 0;
+            memcpy(&fn, buf + BA_COMM_ID_BYTES, 8);
+            if (fn == nonce) {
                 const double age_at_start = (double)(t0.tv_sec - sb.st_mtim.tv_sec) + 1e-9 * (double)(t0.tv_nsec - sb.st_mtim.tv_nsec);
-                if (fn == nonce && (nonce != 0 || age_at_start < 2.0)) {
+                bool take = nonce != 0 || age_at_start < 2.0;
+                if (!take) { // written before this process started: only once it has stayed the same for the grace period
+                    const bool same = have_seen && seen_mtime.tv_sec == sb.st_mtim.tv_sec && seen_mtime.tv_nsec == sb.st_mtim.tv_nsec &&
+                                      memcmp(seen, buf, sizeof buf) == 0;
+                    if (!same) {
+                        memcpy(seen, buf, sizeof buf);
+                        seen_mtime = sb.st_mtim;
+                        seen_since = now;
+                        have_seen = true;
+                    } else if (std::chrono::duration<double>(now - seen_since).count() >= grace_s)
+                        take = true;
+                }
+                if (take) {
                     memcpy(id_out, buf, BA_COMM_ID_BYTES);
                     return BA_OK;
                 }
             }
-        }
+        } else
+            have_seen = false; // (rank 0 has removed it: whatever comes next is new)
+        if (std::chrono::duration<double>(now - begin).count() >= wait_s) break;
         std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
-    fprintf(stderr, "ba_mi355x: no communicator id appeared in %s within 60 s (rank %d)\n", path, rank);
+    fprintf(stderr, "ba_mi355x: no communicator id of this launch appeared in %s within %.0f s (rank %d)\n", path, wait_s, rank);
     return BA_ERR_COMM;
 }
 

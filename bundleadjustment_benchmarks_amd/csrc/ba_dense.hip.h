@@ -1057,8 +1057,9 @@ __global__ __launch_bounds__(256) void k_ldlt_backpair(int ncols, int ld, int zr
 // sentinel, so a consumer polls the very datum it needs and no flag or ordering is involved -- with the 128 x 128 block of
 // L for the next group already in registers; then it solves its own group like k_ldlt_backpair and publishes.  The chain is
 // one hop per group: poll, 64 FMAs per thread, three LDS GEMV phases.  A group only waits for groups dispatched BEFORE it (the last
-// group has the lowest workgroup index), so the launch makes progress whether or not all of it is resident (38 workgroups at
-// config 4, 144 at config 5; the spins are bounded anyway).  x must hold the sentinel on entry (k_post_reduce / k_fill_sentinel).
+// group has the lowest workgroup index) IF workgroups are dispatched in index order -- observed, not promised by HIP: the host caps the
+// grid at one workgroup per CU (ba_ldlt_backsweep: max_groups) so that the whole launch is resident, which is what correctness rests
+// on (38 workgroups at config 4, 144 at config 5; the spins are bounded anyway).  x must hold the sentinel on entry (k_post_reduce / k_fill_sentinel).
 template <typename T>
 __global__ void k_fill_sentinel(int n, T *__restrict__ x)
 {
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
     // the helper (role 1) takes g + 2, g + 4, ..., so it is done one hop BEFORE the chain reaches the group and hands its partial
     // sums over (zh, same sentinel protocol as x) off the critical path.  Each now needs a block every second hop.
     // The LAST group goes first in dispatch order: a group waits for the groups behind it only, so every wait is for a workgroup that
-    // was dispatched earlier -- the sweep makes progress whether or not the whole grid is resident at once.
+    // was dispatched earlier IF dispatch follows the index order (an assumption; the grid is capped to be fully resident regardless).
     // (and a group's helper in front of its main workgroup, which waits for the helper's partial sums)
     const int tid = threadIdx.x, G = nwg >> 1, g = G - 1 - (wg >> 1), role = (wg & 1) ^ 1;
     if (g == skip_group) return;
@@ -1186,9 +1187,13 @@ __global__ __launch_bounds__(256) void k_ldlt_backflow(int ncols, int ld, int zr
 // Host side of the backward sweep on `st`.  armed: x already holds the sentinel (the solver's k_post_reduce does that).
 template <typename T, int NB> inline void ba_ldlt_backsweep_launches(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x);
 
-// max_groups: beyond that many workgroups (two per group) the sweep falls back to a launch per pair of block columns.  (No longer a
-// residency requirement -- k_ldlt_backflow's waits all point at earlier-dispatched workgroups -- but a chain longer than the chip
-// is wide has nothing to gain from one launch.)
+// max_groups: beyond that many workgroups (two per group) the sweep falls back to a launch per pair of block columns.  This cap --
+// callers pass the CU count, one 256-thread workgroup per CU -- IS the correctness condition of the single launch: with the whole
+// grid resident every wait is for a running workgroup.  That k_ldlt_backflow's waits all point at LOWER workgroup indices only helps
+// under the ASSUMPTION that workgroups are dispatched in index order, which is what the hardware is observed to do and what HIP does
+// not promise (MI355X_MICROARCH.md, "Workgroup dispatch": HIP promises nothing about dispatch order); it is not relied on.  A wait
+// that runs out all the same (a GPU shared with another process) raises BA_DEVERR_SWEEP and ba_minimize repeats the trial with one
+// launch per pair (ba_solver_try_step returns BA_ERR_HIP: the step-level seam has no retry).
 // zh: room for 128 scalars per group (the helpers' partial sums), armed with the sentinel like x.
 template <typename T, int NB>
 inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S, const T *Winv, T *x, T *zh, bool armed = false, int max_groups = 256,

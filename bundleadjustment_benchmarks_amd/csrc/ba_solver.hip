@@ -1103,6 +1103,7 @@ template <typename T> struct Solver final : SolverBase {
                     const auto tw = std::chrono::steady_clock::now();
                     hipError_t eq;
                     while ((eq = hipStreamQuery(st)) == hipErrorNotReady) {
+                        (void)drain(); // rows still arrive (up to LM_DEPTH of them): deliver each when it lands, with its own elapsed time
                         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > watchdog_s) {
                             fprintf(stderr, "ba_mi355x: the stream did not drain within %g s -- giving up on this solver (nothing is freed)\n", watchdog_s);
                             poisoned = true;
@@ -1133,7 +1134,8 @@ template <typename T> struct Solver final : SolverBase {
                     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
                 h.trials -= 1; h.fun_evals -= 1; // the failed trial's row does not count
                 h.status = BA_RUNNING; h.stop = 0; h.deverr = 0; h.go = 0; h.timed = 0; h.prev_go = 0;
-                // (h.prev_code stays: it is the decision of the last GOOD trial, and that is what the guard slot must carry again)
+                // (h.prev_code: k_lm_control overwrote it with the FAILED trial's code -- rejected + stop = 2 -- on every shard alike; the
+                // guard slot gets that same value back, so the repeated trial's check "sum == world x mine" holds on both sides)
                 {
                     const T code = (T)h.prev_code;
                     *h_lam = code; // (pinned staging word; lambda itself lives on the device)

@@ -142,9 +142,10 @@ typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scal
 #define BA_COMM_ID_BYTES 128
 int ba_comm_unique_id(void *id_out /* BA_COMM_ID_BYTES */);
 /* Rendezvous through a file for processes started by hand: rank 0 removes whatever an earlier run left at `path`, creates the id and
- * publishes it (O_EXCL temporary file, mode 0600, atomic rename); the others wait up to 60 s for a file that belongs to THIS launch
- * (the nonce of the environment variable BA_COMM_NONCE when the launcher sets one, else: not older than two seconds before the
- * reader's own start).  ba_comm_id_file_done: call after ba_solver_comm_init has returned (it is collective: every rank has the id
+ * publishes it (O_EXCL temporary file, mode 0600, atomic rename); the others wait up to BA_COMM_WAIT_S (60) seconds for a file that
+ * belongs to THIS launch: the nonce of the environment variable BA_COMM_NONCE when the launcher sets one; else a file written after
+ * the reader's PROCESS start (library load, less two seconds) at once, an older one only after it has stayed unchanged for
+ * BA_COMM_GRACE_S (5) seconds -- this launch's rank 0 would have removed a dead run's leftover at its own start.  ba_comm_id_file_done: call after ba_solver_comm_init has returned (it is collective: every rank has the id
  * by then); rank 0 removes the file, so that no id outlives its launch. */
 int ba_comm_id_via_file(const char *path, int rank, void *id_out);
 int ba_comm_id_file_done(const char *path, int rank);

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 evidence, one gpurun call: bench lines of every config, rocprofv3 kernel stats, PMC passes (HBM bytes: FETCH_SIZE and
+# Round evidence, one gpurun call: bench lines of every config, rocprofv3 kernel stats, PMC passes (HBM bytes: FETCH_SIZE and
 # WRITE_SIZE in passes of their own; matrix-core busy cycles) for configs 4, 5 and 3, the FETCH_SIZE control of scripts/fetch_control.hip,
 # the configs run to the reference's own stop next to the oracle (config 4 included) with the quad free run / ensemble of problem-21.
 # usage: scripts/evidence.sh <tag> [part ...]  (parts: bench prof pmc control configs; default all)  -> gpurun_out/<tag>/ ;
 # copy what is to be judged into profiles/ (scripts/evidence_copy.sh <tag>).
 R=$PWD
-O=$R/gpurun_out/${1:-r03ev}
+O=$R/gpurun_out/${1:-r04ev}
 shift
 PARTS=${*:-bench prof pmc control configs}
 mkdir -p $O

@@ -43,4 +43,8 @@ if mdir:
         e["avg_duration_us_in_pmc_pass"] = dur_ns / 1e3
         # 1024 SIMDs; the clock under this load is ~2.35 GHz (in-kernel s_memtime)
         e["mfma_utilisation"] = (v / n) / (1024 * dur_ns * 2.35) if dur_ns > 0 else None
-print(json.dumps({wl: out}, indent=1))
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+# (the sources these kernels were built from: bench.py quotes roofline.traffic only from a pass of the SAME sources)
+print(json.dumps({wl: out, "source_sha16": bench.kernel_source_sha16()}, indent=1))

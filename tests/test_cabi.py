@@ -178,3 +178,85 @@ def test_shard_plan_with_more_ranks_than_points(ba):
     assert plans[0]["p0"] == 0 and plans[-1]["p1"] == 5
     assert sum(q["o1"] - q["o0"] for q in plans) == 12 and sum(q["p1"] - q["p0"] for q in plans) == 5
     assert any(q["p1"] == q["p0"] for q in plans)  # some shards are empty: allowed
+
+
+# ---- rendezvous file of a sharded launch (ba_comm_id_via_file, reader side) ---------------------------------------------
+# The file format is the documented one (128-byte id + 8-byte nonce hash, 0 without BA_COMM_NONCE), so a test can play rank 0 without
+# RCCL.  Each case runs in a fresh process: "process start" is the moment the library is loaded.
+
+_READER = r"""
+import ctypes, os, sys, time
+sys.path.insert(0, %(root)r)
+import bundleadjustment_benchmarks_amd as ba
+L = ba.lib()                      # <- the reader's process start, as the library sees it
+time.sleep(float(sys.argv[2]))    # problem load + solver creation of a big shard
+buf = ctypes.create_string_buffer(128)
+t0 = time.time()
+rc = L.ba_comm_id_via_file(sys.argv[1].encode(), 1, buf)
+print(rc, "%%.2f" %% (time.time() - t0), buf.raw[:4].hex())
+"""
+
+
+def _reader(tmp_path, path, delay, env=None):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "reader.py"
+    script.write_text(_READER % {"root": ROOT})
+    e = dict(os.environ, BA_COMM_WAIT_S="12")
+    e.pop("BA_COMM_NONCE", None)
+    e.update(env or {})
+    return subprocess.Popen([sys.executable, str(script), str(path), str(delay)], stdout=subprocess.PIPE, text=True, env=e)
+
+
+def _publish(path, first4, nonce=0):
+    tmp = str(path) + ".t"
+    with open(tmp, "wb") as f:
+        f.write(bytes(first4) + bytes(124) + int(nonce).to_bytes(8, "little"))
+    os.replace(tmp, path)
+
+
+def test_comm_file_written_before_a_slow_readers_call_is_accepted_at_once(tmp_path):
+    """Rank 0 publishes; the reader reaches ba_comm_id_via_file 3 s later (its shard took that long to load).  Round 3 measured the
+    file's age against the CALL and refused this launch's valid file for 60 s; the yardstick is the reader's process start."""
+    import time
+    path = tmp_path / "comm.id"
+    p = _reader(tmp_path, path, 3.0)
+    time.sleep(1.0)  # (the reader process is up and has loaded the library by now: torch is not imported, ~0.3 s)
+    _publish(path, b"\x01\x02\x03\x04")
+    rc, waited, head = p.communicate(timeout=60)[0].split()
+    assert int(rc) == 0 and head == "01020304" and float(waited) < 1.0, (rc, waited, head)
+
+
+def test_comm_file_left_by_a_dead_run_is_not_taken_while_rank0_replaces_it(tmp_path):
+    import time
+    path = tmp_path / "comm.id"
+    _publish(path, b"\xde\xad\xde\xad")
+    os.utime(path, (time.time() - 100, time.time() - 100))
+    p = _reader(tmp_path, path, 0.0)
+    time.sleep(2.0)  # inside the 5 s grace period: rank 0 of this launch starts, removes the leftover, publishes its own id
+    os.unlink(path)
+    time.sleep(0.3)
+    _publish(path, b"\x0a\x0b\x0c\x0d")
+    rc, waited, head = p.communicate(timeout=60)[0].split()
+    assert int(rc) == 0 and head == "0a0b0c0d", (rc, waited, head)
+
+
+def test_comm_file_of_an_early_rank0_is_taken_after_the_grace_period(tmp_path):
+    """Rank 0 started by hand long before this reader: the file is older than the reader's process, nobody replaces it -- accepted once
+    it has stayed unchanged for BA_COMM_GRACE_S."""
+    import time
+    path = tmp_path / "comm.id"
+    _publish(path, b"\x11\x22\x33\x44")
+    os.utime(path, (time.time() - 30, time.time() - 30))
+    p = _reader(tmp_path, path, 0.0, env={"BA_COMM_GRACE_S": "2"})
+    rc, waited, head = p.communicate(timeout=60)[0].split()
+    assert int(rc) == 0 and head == "11223344" and 1.5 < float(waited) < 6.0, (rc, waited, head)
+
+
+def test_comm_file_with_another_launchs_nonce_is_never_taken(tmp_path):
+    path = tmp_path / "comm.id"
+    _publish(path, b"\x55\x55\x55\x55", nonce=12345)
+    p = _reader(tmp_path, path, 0.0, env={"BA_COMM_NONCE": "this-launch", "BA_COMM_WAIT_S": "3"})
+    rc, waited, head = p.communicate(timeout=60)[0].split()
+    assert int(rc) != 0 and float(waited) >= 2.9
