@@ -332,8 +332,12 @@ def main():
         solver.linearize(True)
         solver.try_step(lam)
         reps = args.phase_reps
-        ph = {"eval_residual": solver.time_phase(0, reps, lam), "eval_jacobian_grad": solver.time_phase(1, reps, lam),
-              "eliminate": solver.time_phase(2, reps, lam), "schur_assembly": solver.time_phase(3, reps, lam),
+        # eval_jacobian_grad: the linearisation as ba_minimize runs it behind an accepted step -- ONE pass that also sums the point part of
+        # J'J / J'r and (CHOLESKY) eliminates the points for the next trial (phase 8); eliminate: the stand-alone elimination of a trial
+        # behind a REJECTED one (the trial behind an accepted step does not launch it); eval_jacobian_grad_separate: the separate
+        # launches of the first, host-synchronous linearisation (phase 1)
+        ph = {"eval_residual": solver.time_phase(0, reps, lam), "eval_jacobian_grad": solver.time_phase(8, reps, lam),
+              "eval_jacobian_grad_separate": solver.time_phase(1, reps, lam), "eliminate": solver.time_phase(2, reps, lam), "schur_assembly": solver.time_phase(3, reps, lam),
               "dense_factor": solver.time_phase(6, max(reps // 4, 2), lam), "back_sweep": solver.time_phase(7, max(reps // 4, 2), lam),
               "backsub_retract": solver.time_phase(5, reps, lam)}
         nblk = (D + 63) // 64

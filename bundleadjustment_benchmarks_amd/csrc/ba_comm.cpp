@@ -1,6 +1,6 @@
 // ba_comm.cpp -- RCCL inside the library: the one exchange step of the sharded LM trial (all-reduce of the packed reduced
 // camera system over xGMI) is issued by the C layer itself on the solver's stream, not by a host-language
-// callback.  The reference has no counterpart (single process, no communication); north_star asks for "a thin C-ABI host layer
+// callback; the distributed factor (BA_DIST_FACTOR) adds ncclReduceScatter and ncclBroadcast.  The reference has no counterpart (single process, no communication); north_star asks for "a thin C-ABI host layer
 // ... with an RCCL all-reduce over xGMI on the reduced camera blocks".
 //
 // librccl.so.1 is opened on first use (dlopen), so that single-GPU users -- the executables, the tests -- neither load nor link
@@ -29,6 +29,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -49,9 +51,11 @@ RcclApi &api()
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.h, "ncclAllReduce");
+    a.Broadcast = (decltype(a.Broadcast))dlsym(a.h, "ncclBroadcast");
+    a.ReduceScatter = (decltype(a.ReduceScatter))dlsym(a.h, "ncclReduceScatter");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
-    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.Broadcast && a.ReduceScatter && a.CommDestroy && a.GetErrorString;
     if (!a.ok) fprintf(stderr, "ba_mi355x: librccl lacks an expected symbol\n");
     return a;
 }
@@ -91,6 +95,27 @@ int ba_rccl_allreduce(void *comm, void *buf, size_t count, int f64, int op, void
     if (!a.ok || !comm) return BA_ERR_COMM;
     const ncclResult_t r = a.AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, op == 0 ? ncclSum : ncclMax, (ncclComm_t)comm, (hipStream_t)stream);
     return r == ncclSuccess ? BA_OK : fail("ncclAllReduce", r);
+}
+
+// in place, on `stream`: `count` scalars from rank `root` to every rank (the distributed factor's panels)
+int ba_rccl_broadcast(void *comm, void *buf, size_t count, int f64, int root, void *stream)
+{
+    RcclApi &a = api();
+    if (!a.ok || !comm) return BA_ERR_COMM;
+    const ncclResult_t r = a.Broadcast(buf, buf, count, f64 ? ncclDouble : ncclFloat, root, (ncclComm_t)comm, (hipStream_t)stream);
+    return r == ncclSuccess ? BA_OK : fail("ncclBroadcast", r);
+}
+
+// in place (ncclReduceScatter's in-place form: recvbuff = sendbuff + rank * count): buf holds world chunks of `count` scalars; on
+// return chunk `rank` of THIS rank's buffer is the sum over the ranks of their chunk `rank` (the other chunks are unspecified)
+int ba_rccl_reduce_scatter(void *comm, void *buf, size_t count, int f64, int rank, void *stream)
+{
+    RcclApi &a = api();
+    if (!a.ok || !comm) return BA_ERR_COMM;
+    const size_t sz = f64 ? 8 : 4;
+    const ncclResult_t r = a.ReduceScatter(buf, (char *)buf + (size_t)rank * count * sz, count, f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)comm,
+                                           (hipStream_t)stream);
+    return r == ncclSuccess ? BA_OK : fail("ncclReduceScatter", r);
 }
 
 extern "C" {

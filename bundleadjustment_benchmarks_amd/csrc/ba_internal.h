@@ -63,5 +63,7 @@ int ba_build_structure(const ba_problem *p, int shard_rank, int shard_world, int
 int ba_rccl_init(void **comm_out, const void *id128, int rank, int world);
 void ba_rccl_destroy(void *comm);
 int ba_rccl_allreduce(void *comm, void *buf, size_t count, int f64, int op, void *stream);
+int ba_rccl_broadcast(void *comm, void *buf, size_t count, int f64, int root, void *stream);
+int ba_rccl_reduce_scatter(void *comm, void *buf, size_t count_per_rank, int f64, int rank, void *stream);
 
 #endif

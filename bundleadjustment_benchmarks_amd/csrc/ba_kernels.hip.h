@@ -61,32 +61,125 @@ template <typename T, bool MAX> __device__ __forceinline__ T block_reduce(T v, T
     return a;
 }
 
+// ---- shared arithmetic of the point elimination (one source for the stand-alone kernels and for the fused linearisation: the
+// same expressions, hence the same bits) ---------------------------------------------------------------------------------------
+// The nine per-observation terms of a point's block: u[0..5] of B^T B (00 01 02 11 12 22) and u[6..8] of B^T r.
+// (fp contract off inside the three helpers: which product of a*b + c*d the compiler fuses is ITS choice per call site -- measured: the
+// fused and the stand-alone kernels made different ones -- so the products are rounded separately here and the bits do not depend on the caller)
+template <typename T> __device__ __forceinline__ void ba_pt_terms(const T (&B)[6], T r0, T r1, T (&u)[9])
+{
+#pragma clang fp contract(off)
+    u[0] = B[0] * B[0] + B[3] * B[3];
+    u[1] = B[0] * B[1] + B[3] * B[4];
+    u[2] = B[0] * B[2] + B[3] * B[5];
+    u[3] = B[1] * B[1] + B[4] * B[4];
+    u[4] = B[1] * B[2] + B[4] * B[5];
+    u[5] = B[2] * B[2] + B[5] * B[5];
+#pragma unroll
+    for (int q = 0; q < 3; q++) u[6 + q] = B[q] * r0 + B[3 + q] * r1;
+}
+// U + lambda I = L D L^T (3 x 3, no pivoting), t = L^-1 g  (BacktrackLevMarqCholesky.h:274-282, point columns first)
+template <typename T> struct ba_chol3_t { T l10, l20, l21, i0, i1, i2, t0, t1, t2; };
+template <typename T> __device__ __forceinline__ ba_chol3_t<T> ba_chol3(T u0, T u1, T u2, T u3, T u4, T u5, T g0, T g1, T g2, T lambda)
+{
+#pragma clang fp contract(off)
+    ba_chol3_t<T> c;
+    const T d0 = u0 + lambda;
+    c.l10 = u1 / d0; c.l20 = u2 / d0;
+    const T d1 = (u3 + lambda) - c.l10 * c.l10 * d0;
+    c.l21 = (u4 - c.l20 * c.l10 * d0) / d1;
+    const T d2 = (u5 + lambda) - c.l20 * c.l20 * d0 - c.l21 * c.l21 * d1;
+    c.i0 = (T)1.0 / d0; c.i1 = (T)1.0 / d1; c.i2 = (T)1.0 / d2;
+    c.t0 = g0; c.t1 = g1 - c.l10 * c.t0; c.t2 = g2 - c.l20 * c.t0 - c.l21 * c.t1;
+    return c;
+}
+// The observation's record: Z = A^T (B L^-T) (9 x 3 row-major), the point's 1 / D, pad -- one burst of 16-byte stores.
+// The record (30 of its 32 scalars) leaves in one burst at the end: a record is two cache lines that only this thread writes, and
+// stores trickling out between the Jacobian loads left them half-written in L2 for a microsecond -- evicted partial lines made 96 MB
+// of HBM writes out of 58 MB at config 4 (rocprofv3 WRITE_SIZE).
+template <typename T> __device__ __forceinline__ void ba_chol_record(const T (&A)[18], const T (&B)[6], T l10, T l20, T l21, T i0, T i1, T i2,
+                                                                     T *__restrict__ rec_i)
+{
+#pragma clang fp contract(off)
+    T Bt[6];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        Bt[3 * rr] = B[3 * rr];
+        Bt[3 * rr + 1] = B[3 * rr + 1] - l10 * Bt[3 * rr];
+        Bt[3 * rr + 2] = B[3 * rr + 2] - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
+    }
+    T z[BA_REC];
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const T a0 = A[c], a1 = A[9 + c];
+        z[3 * c] = a0 * Bt[0] + a1 * Bt[3]; z[3 * c + 1] = a0 * Bt[1] + a1 * Bt[4]; z[3 * c + 2] = a0 * Bt[2] + a1 * Bt[5];
+    }
+    z[BA_REC_DINV] = i0; z[BA_REC_DINV + 1] = i1; z[BA_REC_DINV + 2] = i2;
+    z[BA_REC_DINV + 3] = 0; z[BA_REC_DINV + 4] = 0;
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    vec_t *o = (vec_t *)rec_i;
+    constexpr int VW = 16 / sizeof(T);
+#pragma unroll
+    for (int q = 0; q < BA_REC / VW; q++) {
+        vec_t v;
+#pragma unroll
+        for (int u = 0; u < VW; u++) v[u] = z[VW * q + u];
+        o[q] = v;
+    }
+}
+
 // ---- K1/K2: residual (+ Jacobian) per observation ------------------------------------------------------------
 // BAFunctor::E_pos (src/Optimization/BAFunctor.h:160-178) and dE_pos (:181-297) with poseDerivatives (:126-142),
 // DistortionFunction (src/DistortionFunction.cpp:14-51), transformPointIntoCameraSpace (src/CameraMatrix.cpp:259-261).
 // One thread per observation; camera / point parameters are gathered (observations are point-sorted, so a wave's
 // point reads are near-contiguous and the 15N camera scalars stay in L2), everything else is a coalesced SoA stream.
-template <typename T, bool JAC>
+//
+// eb != nullptr: the workgroups' observation ranges are POINT-ALIGNED (eb[b] .. eb[b + 1], at most 256, whole points: built once on
+// the host) instead of plain runs of 256 -- the same mapping for the residual-only evaluation, so the energy of a point x is the
+// same bits whichever instantiation sums it.  That makes a point's observations neighbours inside ONE workgroup, and the
+// linearisation can finish the point's part of the trial that follows it in the same pass (round 4, VERDICT r3 item 5: "never store
+// J twice"):
+//   FUSE >= 1  U0_j = sum B^T B and g_p = -sum B^T r per point (k_point_prep's work: Jp and r are not read back), the per-observation
+//              terms meeting in LDS and summed by the point's first lane in observation order -- k_point_prep's order, its bits;
+//   FUSE == 2  (CHOLESKY) the point's 3 x 3 LDL^T at the lambda the step control has just left in scal[], t, and every observation's
+//              record Z_i -- k_elim_chol's work for the FIRST trial of the new outer iteration (Jc, Jp are not read back for it);
+//              *fresh = 1 tells that trial's k_elim_chol to leave at once.  Rejected trials re-run k_elim_chol from the stored J.
+template <typename T> struct ba_fuse_args {
+    const int *eb;     // nullptr: plain runs of 256 observations
+    const int *pt_ptr; // first observation of every point (+ end)
+    const T *lam;
+    T *U0, *gp, *rec, *dinv, *tvec, *tri;
+    int *fresh;
+};
+template <typename T, bool JAC, int FUSE = 0>
 __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__restrict__ cam, const T *__restrict__ pts,
                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                                               const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
                                               T *__restrict__ Jp, T *__restrict__ JcA /* [K][20] AoS copy: A (18), r (2) */,
                                               T *__restrict__ partial, const int *__restrict__ go = nullptr,
-                                              T *__restrict__ commit_cam = nullptr, T *__restrict__ commit_pts = nullptr)
+                                              T *__restrict__ commit_cam = nullptr, T *__restrict__ commit_pts = nullptr,
+                                              ba_fuse_args<T> fa = ba_fuse_args<T>{})
 {
+    static_assert(FUSE == 0 || JAC, "the fused point part belongs to the linearisation");
     __shared__ T red[4];
     if (go && *go == 0) return; // device-side LM control: the trial in front of this linearisation was rejected (uniform)
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = fa.eb ? fa.eb[blockIdx.x] : (int)blockIdx.x * 256;
+    const int b1 = fa.eb ? fa.eb[blockIdx.x + 1] : (b0 + 256 < K ? b0 + 256 : K);
+    const int i = b0 + threadIdx.x;
+    const bool valid = i < b1;
     if (commit_cam) { // x = xTest (BacktrackLevMarqQRChol.h:428) rides on the linearisation at xTest: cam / pts ARE xTest here
         const int ncam = 15 * N, ntot = ncam + 3 * Ml;
-        for (int q = i; q < ntot; q += gridDim.x * 256) {
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < ntot; q += gridDim.x * 256) {
             if (q < ncam) commit_cam[q] = cam[q];
             else commit_pts[q - ncam] = pts[q - ncam];
         }
     }
     T e2 = 0;
-    if (i < K) {
-        const int ci = obs_cam[i], pj = obs_pt[i];
+    T Aj[FUSE == 2 ? 18 : 1], Bj[FUSE > 0 ? 6 : 1], ej[2] = {0, 0};
+    int pj = 0;
+    if (valid) {
+        const int ci = obs_cam[i];
+        pj = obs_pt[i];
         T c[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) c[k] = cam[(size_t)k * N + ci];
@@ -110,6 +203,7 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
         const T e0 = r0 * sqrt_psi * rnorm_r, e1 = r1 * sqrt_psi * rnorm_r;
         e2 = e0 * e0 + e1 * e1;
         if (JAC) {
+            ej[0] = e0; ej[1] = e1;
             r[i] = e0;
             r[(size_t)K + i] = e1;
             JcA[(size_t)i * 20 + 18] = e0;
@@ -157,15 +251,64 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
                     Jc[(size_t)(9 + q) * K + i] = t1;
                     JcA[(size_t)i * 20 + q] = t0; // gathered by camera in k_cam_gram: one 160-byte record per observation
                     JcA[(size_t)i * 20 + 9 + q] = t1;
+                    if (FUSE == 2) { Aj[q] = t0; Aj[9 + q] = t1; }
                 } else {
                     Jp[(size_t)(q - 9) * K + i] = t0;
                     Jp[(size_t)(q - 6) * K + i] = t1;
+                    if (FUSE > 0) { Bj[q - 9] = t0; Bj[q - 6] = t1; }
                 }
             }
         }
     }
     e2 = block_reduce<T, false>(e2, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = e2;
+    if constexpr (FUSE > 0) {
+        // the point part: a point's observations are threads tl .. tl + k - 1 of this workgroup (point-aligned ranges)
+        __shared__ T cu[9][256];
+        const int tl = threadIdx.x;
+        {
+            T u[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) u[q] = 0;
+            if (valid) ba_pt_terms<T>(Bj, ej[0], ej[1], u);
+#pragma unroll
+            for (int q = 0; q < 9; q++) cu[q][tl] = u[q];
+        }
+        __syncthreads();
+        const int pfirst = valid ? fa.pt_ptr[pj] : 0;
+        __shared__ T pf[6][256];
+        if (valid && i == pfirst) {
+            const int kk = fa.pt_ptr[pj + 1] - pfirst;
+            T U[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            for (int s = 0; s < kk; s++) { // observation order: k_point_prep's order of additions
+#pragma unroll
+                for (int q = 0; q < 6; q++) U[q] += cu[q][tl + s];
+#pragma unroll
+                for (int q = 0; q < 3; q++) g[q] -= cu[6 + q][tl + s];
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) fa.U0[(size_t)q * Ml + pj] = U[q];
+#pragma unroll
+            for (int q = 0; q < 3; q++) fa.gp[(size_t)q * Ml + pj] = g[q];
+            if (FUSE == 2) {
+                const ba_chol3_t<T> c3 = ba_chol3<T>(U[0], U[1], U[2], U[3], U[4], U[5], g[0], g[1], g[2], *fa.lam);
+                const size_t M = (size_t)Ml;
+                fa.dinv[pj] = c3.i0; fa.dinv[M + pj] = c3.i1; fa.dinv[2 * M + pj] = c3.i2;
+                fa.tvec[pj] = c3.t0; fa.tvec[M + pj] = c3.t1; fa.tvec[2 * M + pj] = c3.t2;
+                fa.tri[pj] = 1; fa.tri[M + pj] = c3.l10; fa.tri[2 * M + pj] = c3.l20;
+                fa.tri[3 * M + pj] = 1; fa.tri[4 * M + pj] = c3.l21; fa.tri[5 * M + pj] = 1;
+                pf[0][tl] = c3.l10; pf[1][tl] = c3.l20; pf[2][tl] = c3.l21; pf[3][tl] = c3.i0; pf[4][tl] = c3.i1; pf[5][tl] = c3.i2;
+            }
+        }
+        if constexpr (FUSE == 2) {
+            __syncthreads();
+            if (valid) {
+                const int fl = pfirst - b0; // the point's first lane
+                ba_chol_record<T>(Aj, Bj, pf[0][fl], pf[1][fl], pf[2][fl], pf[3][fl], pf[4][fl], pf[5][fl], fa.rec + (size_t)i * BA_REC);
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) *fa.fresh = 1;
+        }
+    }
 }
 
 // Utils::showErrorStatistics / showObjective (src/Utils.h:10-68): 4 partial sums per block.
@@ -253,14 +396,12 @@ __device__ __forceinline__ void ba_point_prep_block(int bid, int Ml, int K, cons
 #pragma unroll
             for (int q = 0; q < 6; q++) B[q] = Jp[(size_t)q * K + i];
             const T r0 = r[i], r1 = r[(size_t)K + i];
-            U[0] += B[0] * B[0] + B[3] * B[3];
-            U[1] += B[0] * B[1] + B[3] * B[4];
-            U[2] += B[0] * B[2] + B[3] * B[5];
-            U[3] += B[1] * B[1] + B[4] * B[4];
-            U[4] += B[1] * B[2] + B[4] * B[5];
-            U[5] += B[2] * B[2] + B[5] * B[5];
+            T u[9];
+            ba_pt_terms<T>(B, r0, r1, u); // (shared with the fused linearisation, k_eval<T, true, FUSE>: same terms, same order)
 #pragma unroll
-            for (int q = 0; q < 3; q++) g[q] -= B[q] * r0 + B[3 + q] * r1;
+            for (int q = 0; q < 6; q++) U[q] += u[q];
+#pragma unroll
+            for (int q = 0; q < 3; q++) g[q] -= u[6 + q];
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) U0[(size_t)q * Ml + j] = U[q];
@@ -412,57 +553,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
                                                    const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ U0,
                                                    const T *__restrict__ gp, const T *__restrict__ lam, T *__restrict__ rec,
-                                                   T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri)
+                                                   T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri,
+                                                   const int *__restrict__ fresh = nullptr /* != 0: the fused linearisation has left this trial's records */)
 {
+    if (fresh && *fresh != 0) return; // (uniform)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= K) return;
     const T lambda = *lam;
     const int j = obs_pt[i];
-    const T u0 = U0[j], u1 = U0[(size_t)Ml + j], u2 = U0[2 * (size_t)Ml + j], u3 = U0[3 * (size_t)Ml + j],
-            u4 = U0[4 * (size_t)Ml + j], u5 = U0[5 * (size_t)Ml + j];
-    const T d0 = u0 + lambda;
-    const T l10 = u1 / d0, l20 = u2 / d0;
-    const T d1 = (u3 + lambda) - l10 * l10 * d0;
-    const T l21 = (u4 - l20 * l10 * d0) / d1;
-    const T d2 = (u5 + lambda) - l20 * l20 * d0 - l21 * l21 * d1;
-    const T i0 = (T)1.0 / d0, i1 = (T)1.0 / d1, i2 = (T)1.0 / d2;
-    const T g0 = gp[j], g1 = gp[(size_t)Ml + j], g2 = gp[2 * (size_t)Ml + j];
-    const T t0 = g0, t1 = g1 - l10 * t0, t2 = g2 - l20 * t0 - l21 * t1;
+    const size_t M = (size_t)Ml;
+    const ba_chol3_t<T> c3 = ba_chol3<T>(U0[j], U0[M + j], U0[2 * M + j], U0[3 * M + j], U0[4 * M + j], U0[5 * M + j],
+                                         gp[j], gp[M + j], gp[2 * M + j], lambda);
     if (i == pt_ptr[j]) {
-        dinv[j] = i0; dinv[(size_t)Ml + j] = i1; dinv[2 * (size_t)Ml + j] = i2;
-        tvec[j] = t0; tvec[(size_t)Ml + j] = t1; tvec[2 * (size_t)Ml + j] = t2;
-        tri[j] = 1; tri[(size_t)Ml + j] = l10; tri[2 * (size_t)Ml + j] = l20;
-        tri[3 * (size_t)Ml + j] = 1; tri[4 * (size_t)Ml + j] = l21; tri[5 * (size_t)Ml + j] = 1;
+        dinv[j] = c3.i0; dinv[M + j] = c3.i1; dinv[2 * M + j] = c3.i2;
+        tvec[j] = c3.t0; tvec[M + j] = c3.t1; tvec[2 * M + j] = c3.t2;
+        tri[j] = 1; tri[M + j] = c3.l10; tri[2 * M + j] = c3.l20;
+        tri[3 * M + j] = 1; tri[4 * M + j] = c3.l21; tri[5 * M + j] = 1;
     }
-    T Bt[6];
+    T A[18], B[6];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const T b0 = Jp[(size_t)(3 * rr) * K + i], b1 = Jp[(size_t)(3 * rr + 1) * K + i], b2 = Jp[(size_t)(3 * rr + 2) * K + i];
-        Bt[3 * rr] = b0;
-        Bt[3 * rr + 1] = b1 - l10 * Bt[3 * rr];
-        Bt[3 * rr + 2] = b2 - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
-    }
-    // The record (30 of its 32 scalars) leaves in one burst of 16-byte stores at the end: a record is two cache lines that only this
-    // thread writes, and stores trickling out between the Jacobian loads left them half-written in L2 for a microsecond -- evicted
-    // partial lines made 96 MB of HBM writes out of 58 MB at config 4 (rocprofv3 WRITE_SIZE).
-    T z[BA_REC];
+    for (int q = 0; q < 6; q++) B[q] = Jp[(size_t)q * K + i];
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        const T a0 = Jc[(size_t)c * K + i], a1 = Jc[(size_t)(9 + c) * K + i];
-        z[3 * c] = a0 * Bt[0] + a1 * Bt[3]; z[3 * c + 1] = a0 * Bt[1] + a1 * Bt[4]; z[3 * c + 2] = a0 * Bt[2] + a1 * Bt[5];
-    }
-    z[BA_REC_DINV] = i0; z[BA_REC_DINV + 1] = i1; z[BA_REC_DINV + 2] = i2;
-    z[BA_REC_DINV + 3] = 0; z[BA_REC_DINV + 4] = 0;
-    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-    vec_t *o = (vec_t *)(rec + (size_t)i * BA_REC);
-    constexpr int VW = 16 / sizeof(T);
-#pragma unroll
-    for (int q = 0; q < BA_REC / VW; q++) {
-        vec_t v;
-#pragma unroll
-        for (int u = 0; u < VW; u++) v[u] = z[VW * q + u];
-        o[q] = v;
-    }
+    for (int q = 0; q < 18; q++) A[q] = Jc[(size_t)q * K + i];
+    ba_chol_record<T>(A, B, c3.l10, c3.l20, c3.l21, c3.i0, c3.i1, c3.i2, rec + (size_t)i * BA_REC);
 }
 
 // ---- K4 (QRCHOL / QRKIT left block): Householder QR of [sqrt(lambda) I3 ; (Jp)_j] per point ------------------
@@ -1005,6 +1118,51 @@ __global__ __launch_bounds__(256) void k_pack_lower(int Dp, int ld, T *__restric
     }
 }
 
+// Distributed factor (BA_DIST_FACTOR): the same trapezoid packed OWNER BY OWNER for the reduce-scatter -- block column p belongs to
+// rank p % world and sits at own_off[p] (in units of 64 scalars) in a buffer of `world` chunks of equal length.  Behind the chunks, at
+// `small`: the camera gradient g_c (row D + 1 of the columns, D scalars) and this shard's energy -- needed on EVERY rank, they go
+// through a small all-reduce of their own.  UNPACK: only this rank's block columns come back (the others are overwritten by the
+// owners' broadcast panels as the factorisation reaches them); the summed g_c returns to row D + 1 of every column (k_post_reduce
+// reads it there), the summed energy to scal[etot].
+template <typename T, bool UNPACK>
+__global__ __launch_bounds__(256) void k_pack_owner(int Dp, int D, int ld, T *__restrict__ S, T *__restrict__ buf, const int *__restrict__ own_off,
+                                                    int world, int rank, size_t small, T *__restrict__ scal, int eloc, int etot)
+{
+    const int c = blockIdx.y;          // column
+    const int p = c >> 6, r0 = p << 6; // block column, first kept row
+    const int h = Dp - r0;             // kept rows of this column
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (c == 0) { if (UNPACK) scal[etot] = buf[small + D]; else buf[small + D] = scal[eloc]; }
+        if (c < D) { if (UNPACK) S[(size_t)c * ld + D + 1] = buf[small + c]; else buf[small + c] = S[(size_t)c * ld + D + 1]; }
+    }
+    if (UNPACK && p % world != rank) return;
+    const size_t off = (size_t)64 * (size_t)own_off[p] + (size_t)(c - r0) * h;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < h; r += gridDim.x * 256) {
+        if (UNPACK) { if (r0 + r != D + 1 || c >= D) S[(size_t)c * ld + r0 + r] = buf[off + r]; } // (row D + 1: the all-reduced g_c, written above)
+        else buf[off + r] = S[(size_t)c * ld + r0 + r];
+    }
+}
+
+// One block column's factor pieces, contiguous for ONE broadcast: [L: h x 64 (rows p0 .. of the block column of S) | Y = L D: h x 64
+// (the same rows of Wp) | W = L11^-1: 64 x 64].  grid (ceil(h / 256), 2 * 64 + 1): y < 64 a column of L, < 128 a column of Y, 128 = W.
+template <typename T, int NB, bool UNSTAGE>
+__global__ __launch_bounds__(256) void k_panel_stage(int h, int p0, int ld, T *__restrict__ S, T *__restrict__ Wp, T *__restrict__ Winv, T *__restrict__ stage)
+{
+    const int y = blockIdx.y;
+    if (y == 2 * NB) {
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < NB * NB; q += gridDim.x * 256) {
+            if (UNSTAGE) Winv[q] = stage[(size_t)2 * h * NB + q]; else stage[(size_t)2 * h * NB + q] = Winv[q];
+        }
+        return;
+    }
+    const int j = y < NB ? y : y - NB;
+    T *src = (y < NB ? S + (size_t)(p0 + j) * ld : Wp + (size_t)j * ld) + p0;
+    T *dst = stage + (size_t)(y < NB ? 0 : h * NB) + (size_t)j * h;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < h; r += gridDim.x * 256) {
+        if (UNSTAGE) src[r] = dst[r]; else dst[r] = src[r];
+    }
+}
+
 // ---- K7 + K8 (points): back-substitution, point retraction, rho terms ----------------------------------------
 // dx_p = tri^-1 (dinv o (t - sum_i Z_i^T dx_c[cam_i]))  (src/Eigen_ext/BacktrackLevMarqQRChol.h:343-360);
 // x_test = x + dx_p (src/Optimization/BAFunctor.h:335-338); partial sums of dx^T (lambda dx + JtRes) (:375) and |dx|^2.
@@ -1159,6 +1317,7 @@ template <typename T> struct ba_lm_dev {
     int timed;   // t_ctl / t_end describe the iteration just before this one (not the host-synchronous first linearisation)
     int prev_go; // ... and that iteration linearised
     int prev_code; // decision of the previous trial (accepted + 2 stop): what this shard put into the guard slot of the scalar all-reduce
+    int rec_fresh; // the fused linearisation (k_eval<T, true, 2>) has left the records of the NEXT trial: its k_elim_chol returns at once
 };
 // trial_ticks: t_ctl - previous t_end (elimination ... test energy); ctl_ticks_prev: the control segment (control, x = xTest,
 // linearisation) that preceded this trial; both < 0 when unknown
@@ -1273,6 +1432,7 @@ __global__ __launch_bounds__(256 * BA_LM_JOBS) void k_lm_control(T *__restrict__
     scal[sl.guard] = (T)s.prev_code;
     scal[sl.lambda] = s.lambda;
     row.stop = failed ? 2.0 : (s.stop ? 1.0 : 0.0);
+    s.rec_fresh = 0; // this trial's records are spent; the linearisation behind an accepted step (same control segment) may leave the next ones
     *lm = s;
     host->rows[t % BA_LM_RING] = row;
     host->stop = s.stop;

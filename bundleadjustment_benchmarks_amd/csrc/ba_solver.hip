@@ -168,6 +168,13 @@ template <typename T> struct Solver final : SolverBase {
     struct EvSlot { hipEvent_t e[RING_NE]; };
     EvSlot ring[RING_EV] = {};
     int gK = 0, gM = 0, gB = 0; // grids (observations, points, points x 8 lanes)
+    // Workgroups of k_eval: point-aligned observation ranges (at most 256, whole points) whenever no point has more than 256
+    // observations -- for the residual-only evaluation too, so that an energy is the same bits whichever instantiation sums it.
+    // fuse: the linearisation behind an accepted step then also does the point part of the gradient and (CHOLESKY) the elimination
+    // of the trial that follows (k_eval<T, true, FUSE>); BA_NO_FUSE=1 keeps the separate launches on the same ranges (A/B, bit-equal).
+    int gE = 0;
+    bool fuse = false;
+    DevBuf<int> d_eb;
     bool have_step = false;
     int num_cus = 256; // of the device the solver lives on
     double wall_khz = 1e5;
@@ -210,6 +217,20 @@ template <typename T> struct Solver final : SolverBase {
         if (gM < 1) gM = 1;
         gB = (int)(((size_t)Ml * 8 + 255) / 256);
         if (gB < 1) gB = 1;
+        gE = gK;
+        if (sx.kmax <= 256 && Kl > 0) {
+            std::vector<int> eb(1, 0);
+            int fill = 0; // observations in the current range
+            for (int j = 0; j < Ml; j++) {
+                const int k = sx.pt_ptr[j + 1] - sx.pt_ptr[j];
+                if (fill + k > 256) { eb.push_back(sx.pt_ptr[j]); fill = 0; }
+                fill += k;
+            }
+            eb.push_back(Kl);
+            gE = (int)eb.size() - 1;
+            if ((rc = d_eb.upload(eb))) return rc;
+            fuse = getenv("BA_NO_FUSE") == nullptr;
+        }
         if (kind != BA_CHOLESKY && sx.kmax > 1024) return BA_ERR_ARG; // more than 1024 observations of one point: not supported by k_elim_qr
         if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
@@ -379,7 +400,7 @@ template <typename T> struct Solver final : SolverBase {
         AL(d_slab, (size_t)BA_SLAB * (sx.nchunks > 0 ? sx.nchunks : 1));
         AL(d_S, (size_t)ld * (Dp + 64)); AL(d_Wp, (size_t)4 * ld * NB); AL(d_Winv, (size_t)((D + NB - 1) / NB) * NB * NB); AL(d_dxc, (size_t)2 * Dp + 2 * NB); /* the solution + the back sweep's hand-over vector */ AL(d_dxp, 3 * M1);
         if ((rc = d_flags.alloc((size_t)Dp / NB + 2))) return rc;
-        AL(d_part_e, (size_t)gK); AL(d_part_pm, (size_t)gM);
+        AL(d_part_e, (size_t)gE); AL(d_part_pm, (size_t)gM);
         AL(d_part_bs, (size_t)2 * gB); AL(d_part_st, (size_t)4 * gK); AL(d_scal, NSCAL);
 #undef AL
         HIPCHK(hipMemset(d_S.p, 0, sizeof(T) * d_S.n));
@@ -403,6 +424,21 @@ template <typename T> struct Solver final : SolverBase {
         return ar_fn(ar_user, buf, count, sizeof(T) == 8 ? BA_F64 : BA_F32, op, (void *)st) ? BA_ERR_COMM : BA_OK;
     }
     bool sharded() const { return world > 1 || comm != nullptr; }
+    // (round 4) the distributed factor's collectives: a broadcast from the owner of a block column, a reduce-scatter to the owners
+    int bcast(void *buf, size_t count, int root)
+    {
+        if (world <= 1 && !comm) return BA_OK;
+        if (comm) return ba_rccl_broadcast(comm, buf, count, sizeof(T) == 8, root, (void *)st);
+        if (!ar_fn) return BA_ERR_COMM;
+        return ar_fn(ar_user, buf, count, sizeof(T) == 8 ? BA_F64 : BA_F32, BA_OP_BCAST | (root << 8), (void *)st) ? BA_ERR_COMM : BA_OK;
+    }
+    int reduce_scatter(void *buf, size_t count_per_rank)
+    {
+        if (world <= 1 && !comm) return BA_OK;
+        if (comm) return ba_rccl_reduce_scatter(comm, buf, count_per_rank, sizeof(T) == 8, rank, (void *)st);
+        if (!ar_fn) return BA_ERR_COMM;
+        return ar_fn(ar_user, buf, count_per_rank, sizeof(T) == 8 ? BA_F64 : BA_F32, BA_OP_REDUCE_SCATTER, (void *)st) ? BA_ERR_COMM : BA_OK;
+    }
 
     int fetch_scalars()
     {
@@ -439,22 +475,32 @@ template <typename T> struct Solver final : SolverBase {
 
     // which: 0 = x, 1 = xTest
     // commit (with jac, which = 1): the linearisation AT xTest also performs x = xTest (k_commit's copy rides on k_eval)
-    void launch_eval(bool jac, int which, const int *go = nullptr, bool commit = false)
+    // fused (with jac): the point part of the gradient and, CHOLESKY, the next trial's elimination in the same pass (k_eval<T, true, FUSE>)
+    void launch_eval(bool jac, int which, const int *go = nullptr, bool commit = false, bool fused = false)
     {
         const T tau2 = tau * tau;
-        if (jac)
-            hipLaunchKernelGGL((k_eval<T, true>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go,
-                               commit ? d_cam[0].p : (T *)nullptr, commit ? d_pts[0].p : (T *)nullptr);
-        else
-            hipLaunchKernelGGL((k_eval<T, false>), dim3(gK), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p,
-                               d_obs_cam.p, d_obs_pt.p, d_meas.p, tau2, (T *)nullptr, (T *)nullptr, (T *)nullptr, (T *)nullptr, d_part_e.p, go);
+        ba_fuse_args<T> fa{};
+        fa.eb = d_eb.p; // (nullptr when a point has more than 256 observations: plain runs of 256)
+        fa.pt_ptr = d_pt_ptr.p; fa.lam = d_scal.p + SC_LAMBDA; fa.U0 = d_U0.p; fa.gp = d_gp.p;
+        fa.rec = d_rec.p; fa.dinv = d_dinv.p; fa.tvec = d_tvec.p; fa.tri = d_tri.p; fa.fresh = &d_lm.p->rec_fresh;
+#define BA_EVAL(J, F) hipLaunchKernelGGL((k_eval<T, J, F>), dim3(gE), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p, d_obs_cam.p, d_obs_pt.p, \
+                                         d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go, commit ? d_cam[0].p : (T *)nullptr,              \
+                                         commit ? d_pts[0].p : (T *)nullptr, fa)
+        if (!jac) BA_EVAL(false, 0);
+        else if (!(fused && fuse)) BA_EVAL(true, 0);
+        else if (kind == BA_CHOLESKY) BA_EVAL(true, 2);
+        else BA_EVAL(true, 1);
+#undef BA_EVAL
     }
 
     // tail: the energy reduction that closes the linearisation, as one more block of the last launch (+ the control segment's end stamp)
-    void launch_grad(const int *go = nullptr, const ba_red_job *tail = nullptr)
+    void launch_grad(const int *go = nullptr, const ba_red_job *tail = nullptr, bool points = true /* false: the fused k_eval has done them */)
     {
-        if (sx.ndchunks > 0 && gM <= 2 * num_cus && !no_fold) // a point part of one round of workgroups: both in one launch (k_grad_prep)
+        if (!points) {
+            if (sx.ndchunks > 0)
+                hipLaunchKernelGGL((k_cam_gram<T>), dim3((sx.ndchunks + 7) / 8), dim3(256), 0, st, sx.ndchunks, Kl,
+                                   d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
+        } else if (sx.ndchunks > 0 && gM <= 2 * num_cus && !no_fold) // a point part of one round of workgroups: both in one launch (k_grad_prep)
             hipLaunchKernelGGL((k_grad_prep<T>), dim3(gM + (sx.ndchunks + 7) / 8), dim3(256), 0, st, gM, Ml, Kl, d_pt_ptr.p, d_Jp.p, d_r.p, d_U0.p, d_gp.p,
                                d_part_pm.p, sx.ndchunks, d_dchunk_ptr.p, d_cam_obs.p, d_JcA.p, d_dslab.p, go);
         else {
@@ -497,10 +543,13 @@ template <typename T> struct Solver final : SolverBase {
         // energy sum rides on the last launch of launch_grad (no k_reduce_scalars launch) unless MOREQR's outer QR follows it
         ba_red_jobs jobs{};
         int nj = 0;
-        jobs.j[nj++] = {d_part_e.p, gK, 0, sharded() ? SC_ELOC : SC_ENERGY};
+        jobs.j[nj++] = {d_part_e.p, gE, 0, sharded() ? SC_ELOC : SC_ENERGY};
         const bool tail = go != nullptr && !want_dmax && kind != BA_MOREQR;
-        launch_eval(true, go ? 1 : 0, go, go != nullptr);
-        launch_grad(go, tail ? &jobs.j[0] : nullptr);
+        // behind a trial the point part of J^T r / J^T J and (CHOLESKY) the elimination of the next trial are part of the k_eval launch;
+        // the first, host-synchronous linearisation (lambda0 is not known yet, max diag J^T J is wanted) keeps the separate launches
+        const bool fz = fuse && go != nullptr && !want_dmax;
+        launch_eval(true, go ? 1 : 0, go, go != nullptr, fz);
+        launch_grad(go, tail ? &jobs.j[0] : nullptr, !fz);
         if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
             launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go);
         if (tail) { have_step = false; return BA_OK; }
@@ -522,7 +571,8 @@ template <typename T> struct Solver final : SolverBase {
     {
         if (kind == BA_CHOLESKY) {
             hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
-                               d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+                               d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p,
+                               fuse ? (const int *)&d_lm.p->rec_fresh : (const int *)nullptr);
         } else if (kind == BA_MOREQR) {
             if (Kl > 0) // BacktrackLevMarqMore.h:297-345, the per-trial QR of [R ; sqrt(lambda) I]
                 hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
@@ -574,29 +624,76 @@ template <typename T> struct Solver final : SolverBase {
     }
 
     // ---- distributed factor (BA_DIST_FACTOR=1, sharded LDL^T symbols; SURVEY 8e "consider distributing K6" -- FUNCTIONAL, unmeasured: this
-    // pool gives one GPU).  1-D block-cyclic over the ranks: rank p % world owns block column p.  Per block column: the owner factors
-    // it (k_ldlt_panel: L into S, Y = L D into Wp, the block's inverse into Winv), the three pieces are broadcast as sum all-reduces
-    // over zeroed copies on the other ranks, and every rank applies the panel to the block columns IT owns (k_ldlt_update with the
-    // owner filter).  Behind the last column every rank holds the whole L and runs the back sweep redundantly.  The launch-per-step
-    // kernels: nobody waits for anybody inside a launch; three collectives per block column -- a design to measure once there is a
-    // node, not a speed claim (at D = 2313 the factor is latency-bound and every hop is on its critical path).
+    // pool gives one GPU).  1-D block-cyclic over the ranks: rank p % world owns block column p.
+    //   exchange (round 4): every rank only needs the SUM of the block columns it owns, so the shards' partial
+    //   systems meet in a REDUCE-SCATTER -- the trapezoid packed owner by owner into world chunks of equal length (k_pack_owner), half
+    //   the bytes of the all-reduce per rank -- and the camera gradient + energy (D + 1 scalars, needed everywhere) in a small all-reduce;
+    //   factor: per block column the owner factors it (k_ldlt_panel: L into S, Y = L D into Wp, the block's inverse into Winv), the
+    //   three pieces travel in ONE broadcast from the owner (staged contiguously, k_panel_stage; round 3: three sum all-reduces of zeroed
+    //   copies), and every rank applies the panel to the block columns IT owns (k_ldlt_update with the owner filter).
+    // Behind the last column every rank holds the whole L and runs the back sweep redundantly.  The launch-per-step kernels: nobody
+    // waits for anybody inside a launch; one collective per block column on the factor's critical path -- a design to measure once
+    // there is a node, not a speed claim (at D = 2313 the factor is latency-bound and every hop is on its critical path).
     bool dist_factor = false;
+    DevBuf<T> d_stage;       // one block column's [L | Y | W] for the broadcast
+    DevBuf<int> d_own_off;   // per block column: offset of its first scalar in the owner-packed buffer, as a count of 64-scalar units (fits 32 bits)
+    size_t own_chunk = 0;    // scalars per rank in the owner-packed buffer
+    bool dist_on() const { return dist_factor && sharded() && !dense_qr(); }
+    int dist_setup()
+    {
+        if (d_own_off.p) return BA_OK;
+        const int nbc = Dp / NB;
+        std::vector<size_t> fill((size_t)world, 0);
+        std::vector<int> off((size_t)nbc);
+        for (int p = 0; p < nbc; p++) { off[p] = (int)(fill[p % world] / 64); fill[p % world] += (size_t)64 * (size_t)(Dp - 64 * p); }
+        own_chunk = 0;
+        for (size_t f : fill) own_chunk = std::max(own_chunk, f);
+        for (int p = 0; p < nbc; p++) off[p] += (int)((size_t)(p % world) * own_chunk / 64);
+        int rc;
+        if ((rc = d_own_off.upload(off))) return rc;
+        if ((rc = d_pack.alloc((size_t)world * own_chunk + (size_t)D + 2))) return rc; // behind the chunks: g_c (D) + the energy
+        return d_stage.alloc((size_t)(2 * (size_t)ld + NB) * NB);
+    }
+    size_t dist_small_off() const { return (size_t)world * own_chunk; }
+    // segment A's tail / segment B's head in this mode
+    int launch_dist_pack()
+    {
+        int rc;
+        if ((rc = dist_setup())) return rc;
+        HIPCHK(hipMemsetAsync(d_pack.p, 0, sizeof(T) * (size_t)world * own_chunk, st)); // (the padding behind the shorter chunks)
+        const dim3 g((Dp + 255) / 256 > 8 ? 8 : (Dp + 255) / 256, Dp);
+        hipLaunchKernelGGL((k_pack_owner<T, false>), g, dim3(256), 0, st, Dp, D, ld, d_S.p, d_pack.p, d_own_off.p, world, rank, dist_small_off(), d_scal.p,
+                           (int)SC_ELOC, (int)SC_ENERGY);
+        return BA_OK;
+    }
+    int launch_dist_unpack()
+    {
+        const dim3 g((Dp + 255) / 256 > 8 ? 8 : (Dp + 255) / 256, Dp);
+        hipLaunchKernelGGL((k_pack_owner<T, true>), g, dim3(256), 0, st, Dp, D, ld, d_S.p, d_pack.p, d_own_off.p, world, rank, dist_small_off(), d_scal.p,
+                           (int)SC_ELOC, (int)SC_ENERGY);
+        return BA_OK;
+    }
+    int dist_exchange()
+    {
+        int rc;
+        if ((rc = reduce_scatter(d_pack.p, own_chunk))) return rc;
+        return allreduce(d_pack.p + dist_small_off(), (size_t)D + 1, 0);
+    }
     int launch_factor_solve_dist()
     {
         const int nrows = D + 1, ncols = D, nblk = (ncols + NB - 1) / NB;
-        const size_t colsz = (size_t)ld * NB;
         int rc;
         for (int p = 0; p < nblk; p++) {
-            const int p0 = p * NB, below = nrows - (p0 + NB), npanel = below > 0 ? (below + 63) / 64 : 1;
-            T *wcol = d_Wp.p, *scol = d_S.p + (size_t)p0 * ld, *winv = d_Winv.p + (size_t)p * NB * NB;
-            if (p % world == rank)
+            const int p0 = p * NB, below = nrows - (p0 + NB), npanel = below > 0 ? (below + 63) / 64 : 1, owner = p % world;
+            const int h = Dp - p0; // rows of the block column from its diagonal block down (the rhs row D among them)
+            T *wcol = d_Wp.p, *winv = d_Winv.p + (size_t)p * NB * NB;
+            const dim3 gs((h + 255) / 256, 2 * NB + 1);
+            if (owner == rank) {
                 hipLaunchKernelGGL((k_ldlt_panel<T, NB>), dim3(npanel), dim3(256), 0, st, nrows, ncols, ld, p0, d_S.p, wcol, winv, (int *)nullptr, 0);
-            else {
-                HIPCHK(hipMemsetAsync(wcol, 0, sizeof(T) * colsz, st));
-                HIPCHK(hipMemsetAsync(scol, 0, sizeof(T) * colsz, st));
-                HIPCHK(hipMemsetAsync(winv, 0, sizeof(T) * NB * NB, st));
+                hipLaunchKernelGGL((k_panel_stage<T, NB, false>), gs, dim3(256), 0, st, h, p0, ld, d_S.p, wcol, winv, d_stage.p);
             }
-            if ((rc = allreduce(wcol, colsz, 0)) || (rc = allreduce(scol, colsz, 0)) || (rc = allreduce(winv, (size_t)NB * NB, 0))) return rc;
+            if ((rc = bcast(d_stage.p, (size_t)(2 * h + NB) * NB, owner))) return rc;
+            if (owner != rank) hipLaunchKernelGGL((k_panel_stage<T, NB, true>), gs, dim3(256), 0, st, h, p0, ld, d_S.p, wcol, winv, d_stage.p);
             const int p1 = p0 + NB;
             if (p1 < ncols) {
                 const int nti = (nrows - p1 + 63) / 64, ntj = (ncols - p1 + 63) / 64;
@@ -665,6 +762,8 @@ template <typename T> struct Solver final : SolverBase {
     {
         *h_lam = lambda;
         HIPCHK(hipMemcpyAsync(d_scal.p + SC_LAMBDA, h_lam, sizeof(T), hipMemcpyHostToDevice, st));
+        // a lambda from the host: whatever records a fused linearisation left behind were for another one
+        HIPCHK(hipMemsetAsync(&d_lm.p->rec_fresh, 0, sizeof(int), st));
         return BA_OK;
     }
 
@@ -682,7 +781,7 @@ template <typename T> struct Solver final : SolverBase {
     ba_red_jobs test_energy_jobs() const
     {
         ba_red_jobs jobs{};
-        jobs.j[0] = {d_part_e.p, gK, 0, SC_ETEST};
+        jobs.j[0] = {d_part_e.p, gE, 0, SC_ETEST};
         jobs.j[1] = {d_part_bs.p, gB, 0, SC_RHO_P};
         jobs.j[2] = {d_part_bs.p + gB, gB, 0, SC_DN_P};
         return jobs;
@@ -718,12 +817,14 @@ template <typename T> struct Solver final : SolverBase {
         launch_eliminate();
         if (dense_qr()) { launch_qrkit_build(); return sharded() ? launch_qr_stack_pack() : BA_OK; }
         launch_schur();
+        if (dist_on()) return launch_dist_pack();
         return sharded() ? launch_pack(false) : BA_OK;
     }
     int launch_seg_b()
     {
         int rc;
-        if (sharded() && !dense_qr() && (rc = launch_pack(true))) return rc;
+        if (dist_on()) { if ((rc = launch_dist_unpack())) return rc; }
+        else if (sharded() && !dense_qr() && (rc = launch_pack(true))) return rc;
         if (dense_qr()) { if (sharded()) launch_qr_stack_solve(); else launch_qrkit_solve(); }
         else {
             launch_post_reduce();
@@ -755,6 +856,7 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T2], st));
         if (sharded()) {
             if (dense_qr()) { if ((rc = launch_qr_stack_pack()) || (rc = allreduce(d_qB.p, qb_count(), 0))) return rc; }
+            else if (dist_on()) { if ((rc = launch_dist_pack()) || (rc = dist_exchange()) || (rc = launch_dist_unpack())) return rc; }
             else if ((rc = launch_pack(false)) || (rc = allreduce(d_pack.p, pack_count() + 1, 0)) || (rc = launch_pack(true))) return rc;
         }
         HIPCHK(hipEventRecord(ev[EV_T3], st));
@@ -973,9 +1075,12 @@ template <typename T> struct Solver final : SolverBase {
         {
             if ((rc = run_seg(&g_a, &Solver::launch_seg_a, graphs))) return rc;
             HIPCHK(hipEventRecord(e.e[1], st));
-            if ((rc = allreduce(xchg_ptr(), xchg_count(), 0))) return rc; // reduced camera system (or stack of R factors) + rhs + g_c + energy tail
+            // reduced camera system (or stack of R factors) + rhs + g_c + energy tail; the distributed factor only needs each rank's own
+            // block columns summed: a reduce-scatter (half the bytes) + g_c and the energy in a small all-reduce
+            if (dist_on()) { if ((rc = dist_exchange())) return rc; }
+            else if ((rc = allreduce(xchg_ptr(), xchg_count(), 0))) return rc;
             HIPCHK(hipEventRecord(e.e[2], st));
-            if ((rc = run_seg(&g_b, &Solver::launch_seg_b, graphs))) return rc;
+            if ((rc = run_seg(&g_b, &Solver::launch_seg_b, graphs && !dist_on()))) return rc; // (the distributed factor's collectives sit INSIDE segment B)
             HIPCHK(hipEventRecord(e.e[3], st));
             // test energy, rho denominator, |dx|^2 (point parts) + the guard slot and the error word
             if ((rc = allreduce(d_scal.p + SC_ETEST, N_STEP_SCALARS, 0))) return rc;
@@ -1031,7 +1136,8 @@ template <typename T> struct Solver final : SolverBase {
             h.fun_evals = 1;
             h.lambda = kind == BA_MOREQR ? (T)(1e-6 * std::sqrt(dmax)) : (T)(1e-12 * dmax);
         }
-        if (!h.stop && sharded() && !dense_qr() && !d_pack.p && (rc = d_pack.alloc(pack_count() + 1))) return rc; // (never inside a stream capture)
+        if (!h.stop && dist_on() && (rc = dist_setup())) return rc; // (never inside a stream capture)
+        if (!h.stop && sharded() && !dense_qr() && !d_pack.p && (rc = d_pack.alloc(pack_count() + 1))) return rc;
         if (!h.stop && sharded() && dense_qr() && !d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
         if (!h.stop) {
             h_log->done = 0; h_log->stop = 0; h_log->status = BA_RUNNING;
@@ -1041,7 +1147,7 @@ template <typename T> struct Solver final : SolverBase {
             HIPCHK(hipMemcpyAsync(d_lm.p, &h, sizeof h, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st)); // (h is on the stack)
             // graphs unless the stream cannot be captured (legacy stream) or a host callback sits between the segments anyway
-            const bool graphs = use_graph && st != nullptr && !(dist_factor && sharded()); // (the distributed factor's collectives sit INSIDE segment B)
+            const bool graphs = use_graph && st != nullptr; // (the distributed factor keeps segments A and C as graphs; B holds its collectives)
             auto tlast = std::chrono::steady_clock::now();
             auto drain = [&]() { // table rows that have appeared since the last look
                 const int done = __atomic_load_n(&h_log->done, __ATOMIC_ACQUIRE);
@@ -1220,6 +1326,10 @@ template <typename T> struct Solver final : SolverBase {
                 launch_factor_solve();
                 break;
             case 5: launch_backsub_retract(); break;
+            case 8: // the linearisation as ba_minimize runs it behind an accepted step: fused point part (+ CHOLESKY: the next trial's records)
+                launch_eval(true, 0, nullptr, false, true);
+                launch_grad(nullptr, nullptr, !fuse);
+                break;
             case 6: // dense factorisation only (k_ldlt_panel + k_ldlt_step / k_ldlt_update; QRKIT: the Householder QR + solve): events around it, per rep
             case 7: // backward sweep only (k_ldlt_backflow; QRKIT: nothing, the solve is part of 6)
                 if (dense_qr()) {

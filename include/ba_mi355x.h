@@ -126,10 +126,20 @@ typedef struct {
 /* One row of the reference's table (outputIter, BacktrackLevMarqQRChol.h:84-93): f is the energy BEFORE the step. */
 typedef void (*ba_trial_cb)(void *user, int iter, int accepted, double f, double rho, double lambda, double elapsed_s);
 
-/* Sum (op 0) or max (op 1) all-reduce of `count` scalars of type `scalar` in DEVICE memory across the ranks that
- * shard one problem; called on the host thread between kernels, `stream` is the hipStream_t the solver enqueues on (the
- * callback must order itself against that stream).  A transport supplied by the host layer -- used by the gloo tests; the
- * production transport is RCCL inside the library (ba_solver_comm_init).  Never called when shard_world == 1. */
+/* A collective on `count` scalars of type `scalar` in DEVICE memory across the ranks that shard one problem, in place; called on
+ * the host thread between kernels, `stream` is the hipStream_t the solver enqueues on (the callback must order itself against
+ * that stream).  op (low byte; round 4 added the last two for the distributed factor, BA_DIST_FACTOR):
+ *   BA_OP_SUM / BA_OP_MAX    all-reduce;
+ *   BA_OP_BCAST | root << 8  broadcast of dev_buf[0 .. count) from rank `root`;
+ *   BA_OP_REDUCE_SCATTER     dev_buf holds shard_world chunks of `count` scalars; on return chunk `shard_rank` of THIS rank's buffer
+ *                            is the sum over the ranks of their chunk `shard_rank` (ncclReduceScatter's in-place form; the other
+ *                            chunks are unspecified).
+ * A transport supplied by the host layer -- used by the gloo tests; the production transport is RCCL inside the library
+ * (ba_solver_comm_init: ncclAllReduce / ncclBroadcast / ncclReduceScatter).  Never called when shard_world == 1. */
+#define BA_OP_SUM 0
+#define BA_OP_MAX 1
+#define BA_OP_BCAST 2
+#define BA_OP_REDUCE_SCATTER 3
 typedef int (*ba_allreduce_fn)(void *user, void *dev_buf, size_t count, int scalar, int op, void *stream);
 
 /* ---- communication of a sharded solve (no reference counterpart: the reference is one process) ------------------------- */

@@ -44,15 +44,30 @@ def _worker(rank, world, port, kind, out_q):
         stream = torch.cuda.current_stream()
         s.set_stream(stream.cuda_stream)
 
-        def allreduce(ptr, count, scalar, op, strm):
-            t = torch.as_tensor(DevArray(ptr, count, scalar), device=dev)
+        ops = []
+
+        def collective(ptr, count, scalar, op, strm):
+            """The callback ABI of include/ba_mi355x.h with all four op codes (gloo on host copies; RCCL refuses two ranks on one device)."""
+            code, root = op & 0xff, op >> 8
+            ops.append(code)
+            n = count * world if code == 3 else count  # BA_OP_REDUCE_SCATTER: world chunks of `count`
+            t = torch.as_tensor(DevArray(ptr, n, scalar), device=dev)
             stream.synchronize()
             c = t.cpu()
-            dist.all_reduce(c, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
-            t.copy_(c)
+            if code in (0, 1):
+                dist.all_reduce(c, op=dist.ReduceOp.SUM if code == 0 else dist.ReduceOp.MAX)
+                t.copy_(c)
+            elif code == 2:  # BA_OP_BCAST | root << 8
+                dist.broadcast(c, src=root)
+                t.copy_(c)
+            elif code == 3:  # the rank's own chunk summed over the ranks; the other chunks stay what they were (unspecified by the ABI)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                t[rank * count:(rank + 1) * count].copy_(c[rank * count:(rank + 1) * count])
+            else:
+                return 1
             stream.synchronize()
             return 0
-        s.set_allreduce(allreduce)
+        s.set_allreduce(collective)
         e0, dmax = s.linearize()
         r = s.minimize(max_trials=NTR)
         if rank == 0:
@@ -208,21 +223,37 @@ def _worker_dist_factor(rank, world, port, out_q, ncams=40):
         stream = torch.cuda.current_stream()
         s.set_stream(stream.cuda_stream)
 
-        def allreduce(ptr, count, scalar, op, strm):
-            t = torch.as_tensor(DevArray(ptr, count, scalar), device=dev)
+        ops = []
+
+        def collective(ptr, count, scalar, op, strm):
+            """The callback ABI of include/ba_mi355x.h with all four op codes (gloo on host copies; RCCL refuses two ranks on one device)."""
+            code, root = op & 0xff, op >> 8
+            ops.append(code)
+            n = count * world if code == 3 else count  # BA_OP_REDUCE_SCATTER: world chunks of `count`
+            t = torch.as_tensor(DevArray(ptr, n, scalar), device=dev)
             stream.synchronize()
             c = t.cpu()
-            dist.all_reduce(c, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
-            t.copy_(c)
+            if code in (0, 1):
+                dist.all_reduce(c, op=dist.ReduceOp.SUM if code == 0 else dist.ReduceOp.MAX)
+                t.copy_(c)
+            elif code == 2:  # BA_OP_BCAST | root << 8
+                dist.broadcast(c, src=root)
+                t.copy_(c)
+            elif code == 3:  # the rank's own chunk summed over the ranks; the other chunks stay what they were (unspecified by the ABI)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                t[rank * count:(rank + 1) * count].copy_(c[rank * count:(rank + 1) * count])
+            else:
+                return 1
             stream.synchronize()
             return 0
-        s.set_allreduce(allreduce)
+        s.set_allreduce(collective)
         e0, dmax = s.linearize()
         et, rs, dn = s.try_step(1e-4)
         dxc = s.get(ba.GET_DX)[3 * s.Ml:]
+        n_step = list(ops)
         r = s.minimize(max_trials=5)
         if rank == 0:
-            out_q.put((e0, et, rs, dn, dxc, r["trace"]))
+            out_q.put((e0, et, rs, dn, dxc, r["trace"], n_step))
     finally:
         dist.destroy_process_group()
 
@@ -231,7 +262,8 @@ def _worker_dist_factor(rank, world, port, out_q, ncams=40):
 @pytest.mark.parametrize("world,ncams", [(2, 40), (3, 45)])
 def test_distributed_factor_matches_the_replicated_one(ba, gpu_ok, world, ncams):
     """VERDICT r2 item 9 (SURVEY 8e "consider distributing K6"): BA_DIST_FACTOR=1 factors the reduced camera matrix 1-D block-cyclic
-    over the ranks (owner factors a block column, broadcast, every rank updates its own columns) instead of redundantly.  FUNCTIONAL
+    over the ranks (reduce-scatter of the shards' partial systems to the block-column owners, owner factors a block column, ONE
+    broadcast, every rank updates its own columns) instead of redundantly.  FUNCTIONAL
     check only -- two ranks on one GPU over the callback transport against the single-rank (replicated) factor: camera step to 1e-9,
     test energy, rho denominator, the first LM rows.  No speed claim: unmeasured on more than one GPU."""
     p = ba.Problem.synthetic(ncams, 1500, 6000, 91)
@@ -246,7 +278,7 @@ def test_distributed_factor_matches_the_replicated_one(ba, gpu_ok, world, ncams)
     procs = [ctx.Process(target=_worker_dist_factor, args=(r, world, port, q, ncams)) for r in range(world)]
     for pr in procs:
         pr.start()
-    e0d, etd, rsd, dnd, dxcd, trace = q.get(timeout=500)
+    e0d, etd, rsd, dnd, dxcd, trace, ops = q.get(timeout=500)
     for pr in procs:
         pr.join(120)
         assert pr.exitcode == 0
@@ -254,3 +286,8 @@ def test_distributed_factor_matches_the_replicated_one(ba, gpu_ok, world, ncams)
     assert np.linalg.norm(dxcd - dxc) < 1e-9 * np.linalg.norm(dxc)
     assert abs(etd - et) < 1e-9 * et and abs(rsd - rs) < 1e-7 * abs(rs) and abs(dnd - dn) < 1e-9 * dn
     assert np.array_equal(trace[:, :2], ref["trace"][:, :2]) and np.allclose(trace[:3, 2], ref["trace"][:3, 2], rtol=1e-7)
+    # (round 4) the collectives of linearize + ONE step: 3 all-reduces of the first linearisation (energy, column norms, their max), then
+    # the exchange as ONE reduce-scatter (op 3: each rank only needs its own block columns summed) + a small all-reduce (g_c, energy),
+    # ONE broadcast (op 2) per block column -- round 3 made three sum all-reduces of zeroed copies of each -- and the scalar all-reduce
+    nblk = (9 * ncams + 63) // 64
+    assert ops == [0, 0, 1] + [3, 0] + [2] * nblk + [0], ops

@@ -490,3 +490,64 @@ def test_fused_factor_paths(ba, O, gpu_ok, ncams, with_oracle_step):
         st = O.step(O.CHOLESKY, po, Jc, Jp, f, lam)
         assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
+
+
+# ---- round 4: the fused linearisation (k_eval<T, true, FUSE>) ----------------------------------------------------------------------
+@pytest.mark.parametrize("kind,trials", [(2, 40), (1, 30), (3, 16), (0, 6)])
+def test_fused_linearisation_is_bit_equal_to_the_separate_launches(ba, gpu_ok, prob21, monkeypatch, kind, trials):
+    """Behind an accepted step ba_minimize linearises with ONE pass over the observations that also sums the point part of J^T J and
+    J^T r and -- CHOLESKY -- eliminates the points for the trial that follows (k_point_prep and the first k_elim_chol are gone from
+    that path).  BA_NO_FUSE=1 (read at solver creation) keeps the separate launches on the same point-aligned
+    observation ranges.  Same terms, same order of additions, one source for the shared arithmetic: the LM tables -- accepted AND
+    rejected trials (problem-21 CHOLESKY meets its first rejections before row 40) -- are the same BITS, and so is the state left behind."""
+    out = []
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("BA_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("BA_NO_FUSE", raising=False)
+        s = ba.Solver(prob21, kind, ba.F64)
+        r = s.minimize(max_trials=trials)
+        out.append((r["trace"][:, :5].copy(), s.get(ba.GET_CAMS).copy(), s.get(ba.GET_POINTS).copy(), r["energy"]))
+        del s
+    a, b = out
+    assert len(a[0]) == trials
+    if kind == 2:
+        assert (a[0][:, 1] == 0).any(), "the comparison is meant to cross rejected trials"
+    assert np.array_equal(a[0], b[0]), np.argwhere(a[0] != b[0])[:4]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_fused_linearisation_handles_ragged_input_and_long_tracks(ba, gpu_ok, monkeypatch):
+    """Points without observations, single observations, a blind camera, unsorted input (the ragged problem) and tracks of up to 250
+    observations -- a point-aligned range holds at most 256 -- through the fused path and the separate launches: the same bits.  A
+    track beyond 256 observations switches the fusion off for the problem (plain ranges of 256), and the run still works."""
+    probs = [_ragged_problem(ba)]
+    p = ba.Problem.synthetic(12, 300, 1200, 78)
+    a = p.arrays()
+    rng = np.random.default_rng(6)
+    for tracks in (((7, 250), (8, 200), (150, 130)), ((7, 300),)):
+        cam_idx, pt_idx, meas = list(a["cam_idx"]), list(a["pt_idx"]), [tuple(m) for m in a["meas"].reshape(-1, 2)]
+        for j, want in tracks:
+            mine = [i for i in range(p.K) if a["pt_idx"][i] == j]
+            for n in range(want - len(mine)):
+                src = mine[n % len(mine)]
+                cam_idx.append(a["cam_idx"][src]); pt_idx.append(j)
+                m = a["meas"].reshape(-1, 2)[src] + rng.normal(0, 0.3, 2)
+                meas.append((m[0], m[1]))
+        probs.append(ba.Problem.from_arrays(p.N, p.M, len(cam_idx), np.array(cam_idx, np.int32), np.array(pt_idx, np.int32),
+                                            np.array(meas, np.float64).ravel(), a["cams9"], a["pts"]))
+    for pr in probs:
+        out = []
+        for nofuse in (False, True):
+            if nofuse:
+                monkeypatch.setenv("BA_NO_FUSE", "1")
+            else:
+                monkeypatch.delenv("BA_NO_FUSE", raising=False)
+            s = ba.Solver(pr, ba.CHOLESKY, ba.F64)
+            r = s.minimize(max_trials=12)
+            out.append((r["trace"][:, :5].copy(), s.get(ba.GET_POINTS).copy()))
+            del s
+        assert len(out[0][0]) == 12 and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        acc = out[0][0][out[0][0][:, 1] == 1]
+        assert len(acc) >= 3 and np.all(np.diff(acc[:, 2]) < 0)
