@@ -64,19 +64,23 @@ template <typename T, bool MAX> __device__ __forceinline__ T block_reduce(T v, T
 // ---- shared arithmetic of the point elimination (one source for the stand-alone kernels and for the fused linearisation: the
 // same expressions, hence the same bits) ---------------------------------------------------------------------------------------
 // The nine per-observation terms of a point's block: u[0..5] of B^T B (00 01 02 11 12 22) and u[6..8] of B^T r.
-// (fp contract off inside the three helpers: which product of a*b + c*d the compiler fuses is ITS choice per call site -- measured: the
-// fused and the stand-alone kernels made different ones -- so the products are rounded separately here and the bits do not depend on the caller)
+// (Every fused multiply-add of the three helpers is written out and contraction is off inside them: which product of a*b + c*d the
+// compiler fuses is ITS choice per call site -- measured: the fused and the stand-alone kernels made different ones -- and leaving
+// the fusing out altogether cost accuracy that the referee tests see (d1 = (u3 + lambda) - l10^2 d0 cancels).  So: one rounding per
+// fma() below, the same bits whoever calls.)
+__device__ __forceinline__ double ba_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float ba_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename T> __device__ __forceinline__ void ba_pt_terms(const T (&B)[6], T r0, T r1, T (&u)[9])
 {
 #pragma clang fp contract(off)
-    u[0] = B[0] * B[0] + B[3] * B[3];
-    u[1] = B[0] * B[1] + B[3] * B[4];
-    u[2] = B[0] * B[2] + B[3] * B[5];
-    u[3] = B[1] * B[1] + B[4] * B[4];
-    u[4] = B[1] * B[2] + B[4] * B[5];
-    u[5] = B[2] * B[2] + B[5] * B[5];
+    u[0] = ba_fma(B[0], B[0], B[3] * B[3]);
+    u[1] = ba_fma(B[0], B[1], B[3] * B[4]);
+    u[2] = ba_fma(B[0], B[2], B[3] * B[5]);
+    u[3] = ba_fma(B[1], B[1], B[4] * B[4]);
+    u[4] = ba_fma(B[1], B[2], B[4] * B[5]);
+    u[5] = ba_fma(B[2], B[2], B[5] * B[5]);
 #pragma unroll
-    for (int q = 0; q < 3; q++) u[6 + q] = B[q] * r0 + B[3 + q] * r1;
+    for (int q = 0; q < 3; q++) u[6 + q] = ba_fma(B[q], r0, B[3 + q] * r1);
 }
 // U + lambda I = L D L^T (3 x 3, no pivoting), t = L^-1 g  (BacktrackLevMarqCholesky.h:274-282, point columns first)
 template <typename T> struct ba_chol3_t { T l10, l20, l21, i0, i1, i2, t0, t1, t2; };
@@ -86,11 +90,11 @@ template <typename T> __device__ __forceinline__ ba_chol3_t<T> ba_chol3(T u0, T 
     ba_chol3_t<T> c;
     const T d0 = u0 + lambda;
     c.l10 = u1 / d0; c.l20 = u2 / d0;
-    const T d1 = (u3 + lambda) - c.l10 * c.l10 * d0;
-    c.l21 = (u4 - c.l20 * c.l10 * d0) / d1;
-    const T d2 = (u5 + lambda) - c.l20 * c.l20 * d0 - c.l21 * c.l21 * d1;
+    const T d1 = ba_fma(-(c.l10 * c.l10), d0, u3 + lambda);
+    c.l21 = ba_fma(-(c.l20 * c.l10), d0, u4) / d1;
+    const T d2 = ba_fma(-(c.l21 * c.l21), d1, ba_fma(-(c.l20 * c.l20), d0, u5 + lambda));
     c.i0 = (T)1.0 / d0; c.i1 = (T)1.0 / d1; c.i2 = (T)1.0 / d2;
-    c.t0 = g0; c.t1 = g1 - c.l10 * c.t0; c.t2 = g2 - c.l20 * c.t0 - c.l21 * c.t1;
+    c.t0 = g0; c.t1 = ba_fma(-c.l10, c.t0, g1); c.t2 = ba_fma(-c.l21, c.t1, ba_fma(-c.l20, c.t0, g2));
     return c;
 }
 // The observation's record: Z = A^T (B L^-T) (9 x 3 row-major), the point's 1 / D, pad -- one burst of 16-byte stores.
@@ -105,14 +109,14 @@ template <typename T> __device__ __forceinline__ void ba_chol_record(const T (&A
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         Bt[3 * rr] = B[3 * rr];
-        Bt[3 * rr + 1] = B[3 * rr + 1] - l10 * Bt[3 * rr];
-        Bt[3 * rr + 2] = B[3 * rr + 2] - l20 * Bt[3 * rr] - l21 * Bt[3 * rr + 1];
+        Bt[3 * rr + 1] = ba_fma(-l10, Bt[3 * rr], B[3 * rr + 1]);
+        Bt[3 * rr + 2] = ba_fma(-l21, Bt[3 * rr + 1], ba_fma(-l20, Bt[3 * rr], B[3 * rr + 2]));
     }
     T z[BA_REC];
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const T a0 = A[c], a1 = A[9 + c];
-        z[3 * c] = a0 * Bt[0] + a1 * Bt[3]; z[3 * c + 1] = a0 * Bt[1] + a1 * Bt[4]; z[3 * c + 2] = a0 * Bt[2] + a1 * Bt[5];
+        z[3 * c] = ba_fma(a0, Bt[0], a1 * Bt[3]); z[3 * c + 1] = ba_fma(a0, Bt[1], a1 * Bt[4]); z[3 * c + 2] = ba_fma(a0, Bt[2], a1 * Bt[5]);
     }
     z[BA_REC_DINV] = i0; z[BA_REC_DINV + 1] = i1; z[BA_REC_DINV + 2] = i2;
     z[BA_REC_DINV + 3] = 0; z[BA_REC_DINV + 4] = 0;
@@ -151,7 +155,9 @@ template <typename T> struct ba_fuse_args {
     T *U0, *gp, *rec, *dinv, *tvec, *tri;
     int *fresh;
 };
-template <typename T, bool JAC, int FUSE = 0>
+// SOA = false (CHOLESKY): the camera blocks are kept in the AoS records JcA alone -- k_cam_gram gathers them by camera, k_elim_chol reads
+// its own record -- and the 18 SoA streams Jc (144 of the 624 bytes this kernel writes per observation when fused) are not written.
+template <typename T, bool JAC, int FUSE = 0, bool SOA = true>
 __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__restrict__ cam, const T *__restrict__ pts,
                                               const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                                               const T *__restrict__ meas, T tau2, T *__restrict__ r, T *__restrict__ Jc,
@@ -247,8 +253,10 @@ __global__ __launch_bounds__(256) void k_eval(int K, int N, int Ml, const T *__r
                 const T t0 = o00 * Jb[q] + o01 * Jb[12 + q];
                 const T t1 = o01 * Jb[q] + o11 * Jb[12 + q];
                 if (q < 9) {
-                    Jc[(size_t)q * K + i] = t0;
-                    Jc[(size_t)(9 + q) * K + i] = t1;
+                    if (SOA) {
+                        Jc[(size_t)q * K + i] = t0;
+                        Jc[(size_t)(9 + q) * K + i] = t1;
+                    }
                     JcA[(size_t)i * 20 + q] = t0; // gathered by camera in k_cam_gram: one 160-byte record per observation
                     JcA[(size_t)i * 20 + 9 + q] = t1;
                     if (FUSE == 2) { Aj[q] = t0; Aj[9 + q] = t1; }
@@ -551,7 +559,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_vdiag(int N, cons
 // writes the per-point factors.
 template <typename T>
 __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
-                                                   const T *__restrict__ Jc, const T *__restrict__ Jp, const T *__restrict__ U0,
+                                                   const T *__restrict__ JcA /* [K][20] */, const T *__restrict__ Jp, const T *__restrict__ U0,
                                                    const T *__restrict__ gp, const T *__restrict__ lam, T *__restrict__ rec,
                                                    T *__restrict__ dinv, T *__restrict__ tvec, T *__restrict__ tri,
                                                    const int *__restrict__ fresh = nullptr /* != 0: the fused linearisation has left this trial's records */)
@@ -573,8 +581,18 @@ __global__ __launch_bounds__(256) void k_elim_chol(int K, int Ml, const int *__r
     T A[18], B[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) B[q] = Jp[(size_t)q * K + i];
+    { // the observation's own AoS record (A: 18 scalars, then its residual): 16-byte loads of the 160-byte (fp32: 80) record
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int VW = 16 / sizeof(T);
+        const vec_t *src = (const vec_t *)(JcA + (size_t)i * 20);
 #pragma unroll
-    for (int q = 0; q < 18; q++) A[q] = Jc[(size_t)q * K + i];
+        for (int q = 0; q < 20 / VW; q++) {
+            const vec_t v = src[q];
+#pragma unroll
+            for (int u = 0; u < VW; u++)
+                if (VW * q + u < 18) A[VW * q + u] = v[u];
+        }
+    }
     ba_chol_record<T>(A, B, c3.l10, c3.l20, c3.l21, c3.i0, c3.i1, c3.i2, rec + (size_t)i * BA_REC);
 }
 

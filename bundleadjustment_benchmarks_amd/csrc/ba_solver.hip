@@ -371,7 +371,7 @@ template <typename T> struct Solver final : SolverBase {
             return rc;
         const size_t K1 = Kl > 0 ? Kl : 1, M1 = Ml > 0 ? Ml : 1;
 #define AL(buf, n) if ((rc = buf.alloc(n))) return rc
-        AL(d_r, 2 * K1); AL(d_Jc, 18 * K1); AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1);
+        AL(d_r, 2 * K1); if (kind != BA_CHOLESKY) AL(d_Jc, 18 * K1); /* CHOLESKY: JcA alone */ AL(d_JcA, 20 * K1); AL(d_Jp, 6 * K1); AL(d_U0, 6 * M1); AL(d_gp, 3 * M1);
         AL(d_V, (size_t)81 * N); AL(d_gc, (size_t)D);
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
@@ -483,13 +483,14 @@ template <typename T> struct Solver final : SolverBase {
         fa.eb = d_eb.p; // (nullptr when a point has more than 256 observations: plain runs of 256)
         fa.pt_ptr = d_pt_ptr.p; fa.lam = d_scal.p + SC_LAMBDA; fa.U0 = d_U0.p; fa.gp = d_gp.p;
         fa.rec = d_rec.p; fa.dinv = d_dinv.p; fa.tvec = d_tvec.p; fa.tri = d_tri.p; fa.fresh = &d_lm.p->rec_fresh;
-#define BA_EVAL(J, F) hipLaunchKernelGGL((k_eval<T, J, F>), dim3(gE), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p, d_obs_cam.p, d_obs_pt.p, \
+#define BA_EVAL(J, F, ...) hipLaunchKernelGGL((k_eval<T, J, F, ##__VA_ARGS__>), dim3(gE), dim3(256), 0, st, Kl, N, Ml, d_cam[which].p, d_pts[which].p, d_obs_cam.p, d_obs_pt.p, \
                                          d_meas.p, tau2, d_r.p, d_Jc.p, d_Jp.p, d_JcA.p, d_part_e.p, go, commit ? d_cam[0].p : (T *)nullptr,              \
                                          commit ? d_pts[0].p : (T *)nullptr, fa)
+        // (CHOLESKY keeps the camera blocks in the AoS records alone: SOA = false, d_Jc is not even allocated)
         if (!jac) BA_EVAL(false, 0);
-        else if (!(fused && fuse)) BA_EVAL(true, 0);
-        else if (kind == BA_CHOLESKY) BA_EVAL(true, 2);
-        else BA_EVAL(true, 1);
+        else if (kind == BA_CHOLESKY) { if (fused && fuse) BA_EVAL(true, 2, false); else BA_EVAL(true, 0, false); }
+        else if (fused && fuse) BA_EVAL(true, 1);
+        else BA_EVAL(true, 0);
 #undef BA_EVAL
     }
 
@@ -570,7 +571,7 @@ template <typename T> struct Solver final : SolverBase {
     void launch_eliminate()
     {
         if (kind == BA_CHOLESKY) {
-            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_Jp.p,
+            hipLaunchKernelGGL((k_elim_chol<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_JcA.p, d_Jp.p,
                                d_U0.p, d_gp.p, d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p,
                                fuse ? (const int *)&d_lm.p->rec_fresh : (const int *)nullptr);
         } else if (kind == BA_MOREQR) {
@@ -946,6 +947,12 @@ template <typename T> struct Solver final : SolverBase {
         }
         case BA_GET_JC: {
             if (n != 18 * (size_t)Kl) return BA_ERR_ARG;
+            if (kind == BA_CHOLESKY) { // the AoS records [Kl][20] are the only copy
+                if ((rc = dl(d_JcA.p, 20 * (size_t)Kl, h))) return rc;
+                for (int i = 0; i < Kl; i++)
+                    for (int q = 0; q < 18; q++) out[18 * (size_t)i + q] = h[20 * (size_t)i + q];
+                return BA_OK;
+            }
             if ((rc = dl(d_Jc.p, 18 * (size_t)Kl, h))) return rc;
             for (int i = 0; i < Kl; i++)
                 for (int q = 0; q < 18; q++) out[18 * (size_t)i + q] = h[(size_t)q * Kl + i];
@@ -1358,7 +1365,7 @@ template <typename T> struct Solver final : SolverBase {
         HIPCHK(hipEventRecord(ev[EV_T1], st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
-        *ms = (phase >= 6 ? acc_ms : ev_ms(EV_T0, EV_T1)) / reps;
+        *ms = ((phase == 6 || phase == 7) ? acc_ms : ev_ms(EV_T0, EV_T1)) / reps;
         have_step = false;
         return BA_OK;
     }
