@@ -899,7 +899,13 @@ __device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned o
     x1 = ba_bufload(r, off + 4, (const float *)nullptr);
     x2 = ba_bufload(r, off + 8, (const float *)nullptr);
 }
-template <typename T, bool SCALED /* dinv != 1: CHOLESKY */>
+// KO (knock-out experiment only, BA_SCHUR_KNOCKOUT=1|2: wrong results, the time tells): 1 = every ROW record is read from the first 1024
+// records (always cache-resident), 2 = every COLUMN record, 3 = both -- what an order of the work that read that side once per camera could save at most.
+// GB: groups of four entries per batch = what one memory round trip brings in per wavefront (two batches in flight).  The kernel is
+// LATENCY-bound, not traffic-bound -- round 4's knock-outs at config 5: every record gather served from cache, 2.19 -> 1.71 ms -- so
+// where the grid runs two workgroups per CU (records beyond the Infinity Cache: 256 registers per wavefront are there) the batches
+// are twice or four times as deep.
+template <typename T, bool SCALED /* dinv != 1: CHOLESKY */, int KO = 0, int GB = 2>
 __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wave_ptr, int nband, const int4 *__restrict__ chunk_info,
                                                      const int2 *__restrict__ ent, const T *__restrict__ rec, unsigned rec_bytes,
                                                      const T *__restrict__ tvec, int Ml, T *__restrict__ slab, const T *__restrict__ V,
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wav
         acc_t acc;
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = 0;
-        constexpr int GB = 2; // groups of four entries per batch
+        // (GB groups of four entries per batch: template parameter)
         struct batch_t { T a[3 * GB], d[3 * GB], b[3 * GB]; };
         auto fetch = [&](int t0, batch_t &o) { // operands of the entries 4 t0 .. 4 (t0 + GB) - 1: lane (i, k) takes entry k of each group
 #pragma unroll
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wav
                 const int es = ok ? e : n - 1;
                 const int ia = __shfl(ia_l, es, 64), ibr = __shfl(ib_l, es, 64);
                 const bool self = ibr < 0; // self entry: the column observation is the row observation, ibr = ~point
-                const unsigned ra = (unsigned)ia * RB, rb = (unsigned)(self ? ia : ibr) * RB;
+                const unsigned ra = (unsigned)((KO & 1) ? (ia & 1023) : ia) * RB, rb = (unsigned)((KO & 2) ? ((self ? ia : ibr) & 1023) : (self ? ia : ibr)) * RB;
                 const unsigned oa = (ok && la) ? ra + lane_off : OOB, ob = (ok && la) ? rb + lane_off : OOB;
                 const unsigned od = (ok && la) ? ra + BA_REC_DINV * SZ : OOB;
 #ifdef BA_SCHUR_NARROW_LOADS

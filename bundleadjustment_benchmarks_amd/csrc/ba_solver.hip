@@ -129,7 +129,7 @@ template <typename T> struct Solver final : SolverBase {
     int schur_window = 0;
     int nred = 0;
     const bool no_fold = getenv("BA_NO_FOLD") != nullptr; // dev switch: every launch of its own again (A/B timing on one box)
-    int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1;
+    int schur_grid = 1, schur_wgs = 4 /* workgroups of k_schur_pairs per CU */, schur_bands = 8, schur_nband = 1, schur_gb = 2 /* groups of four entries per batch */;
     // state: x = d_cam[0], d_pts[0]; xTest = d_cam[1], d_pts[1] (x = xTest is a device-side copy, k_commit)
     // linearisation at x (r, J, J^T r, block diagonals, MOREQR's outer factors): one set
     DevBuf<T> d_r, d_Jc, d_Jp, d_JcA, d_U0, d_gp, d_V, d_gc, d_rec0, d_dinv0, d_tvec0, d_tri0;
@@ -263,6 +263,7 @@ template <typename T> struct Solver final : SolverBase {
             // memory, and fewer wavefronts in flight walking the pair list side by side leave more of a row camera's records in the
             // L2 (2.23 -> 2.07 ms at config 5; nothing either way at config 4, whose 58 MB of records stay in the Infinity Cache).
             if ((unsigned long long)Kl * BA_REC * sizeof(T) > (256ull << 20)) { schur_wgs = 2; schur_window = 1; }
+            if (const char *ev = getenv("BA_SCHUR_GB")) schur_gb = atoi(ev); // (A/B only: deeper batches measured SLOWER at configs 4 and 5, profiles/EXPERIMENTS.md 4)
             if (const char *ev = getenv("BA_SCHUR_WGS")) schur_wgs = std::max(1, std::min(8, atoi(ev)));
             if (const char *ev = getenv("BA_SCHUR_BANDS")) schur_bands = atoi(ev);
             // Chunks dealt to the wavefronts of the persistent pair kernel, longest first, always to the least loaded wavefront
@@ -272,8 +273,8 @@ template <typename T> struct Solver final : SolverBase {
             {
                 // every wavefront of the persistent grid must be resident at once (the dealing assumes they run side by side)
                 int nb = 0;
-                const hipError_t oe = kind == BA_CHOLESKY ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, true>, 256, 0)
-                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, false>, 256, 0);
+                const hipError_t oe = kind == BA_CHOLESKY ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, true, 0, 2>, 256, 0)
+                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_schur_pairs<T, false, 0, 2>, 256, 0);
                 if (oe == hipSuccess && nb >= 1) schur_wgs = std::min(schur_wgs, nb);
             }
             schur_grid = std::max(1, std::min((sx.nchunks + 3) / 4, schur_wgs * num_cus));
@@ -611,10 +612,16 @@ template <typename T> struct Solver final : SolverBase {
         if (sx.nchunks > 0) {
             // persistent: schur_wgs workgroups per CU, every wavefront walks its own balanced list of chunks (see k_schur_pairs)
             const dim3 gp(schur_grid);
-#define BA_PAIRS(SC) hipLaunchKernelGGL((k_schur_pairs<T, SC>), gp, dim3(256), 0, st, d_wave_ptr.p, schur_nband, d_chunk_info.p, d_ent.p, d_rec.p, \
-                                        (unsigned)(sizeof(T) * d_rec.n), d_tvec.p, Ml, d_slab.p, d_V.p, d_gc.p, D, ld, d_S.p)
+#define BA_PAIRS(SC, KO_, GB_) hipLaunchKernelGGL((k_schur_pairs<T, SC, KO_, GB_>), gp, dim3(256), 0, st, d_wave_ptr.p, schur_nband, d_chunk_info.p, d_ent.p, d_rec.p, \
+                                                  (unsigned)(sizeof(T) * d_rec.n), d_tvec.p, Ml, d_slab.p, d_V.p, d_gc.p, D, ld, d_S.p)
             // SCALED: CHOLESKY is the only symbol whose point blocks carry a diagonal D (dinv != 1)
-            if (kind == BA_CHOLESKY) BA_PAIRS(true); else BA_PAIRS(false);
+            static const int ko = getenv("BA_SCHUR_KNOCKOUT") ? atoi(getenv("BA_SCHUR_KNOCKOUT")) : 0; // (experiment: wrong results, see k_schur_pairs)
+            if (ko == 1) BA_PAIRS(false, 1, 2);
+            else if (ko == 2) BA_PAIRS(false, 2, 2);
+            else if (ko == 3) BA_PAIRS(false, 3, 2);
+            else if (schur_gb == 8) { if (kind == BA_CHOLESKY) BA_PAIRS(true, 0, 8); else BA_PAIRS(false, 0, 8); }
+            else if (schur_gb == 4) { if (kind == BA_CHOLESKY) BA_PAIRS(true, 0, 4); else BA_PAIRS(false, 0, 4); }
+            else if (kind == BA_CHOLESKY) BA_PAIRS(true, 0, 2); else BA_PAIRS(false, 0, 2);
 #undef BA_PAIRS
         }
         const int post_blocks = lamf ? (Dp + 2) / 3 : 0;
