@@ -893,8 +893,10 @@ __device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned o
 }
 __device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned off, float &x0, float &x1, float &x2)
 {
-    // (three 4-byte requests inside ONE 128-byte line: a 12-byte load gave wrong sums here and was not pursued -- the fp32 record is
-    // a single cache line, there is no second request to save)
+    // (three 4-byte requests inside ONE 128-byte line.  A 12-byte load gave wrong sums here in round 3; round 4 found why
+    // (scripts/experiments/buf96_trigger.hip): ROCm 7.2's clang narrows __builtin_amdgcn_raw_buffer_load_b96 to ONE buffer_load_dword
+    // and copies that dword into all three results when the elements are bit-cast to float one by one -- a compiler defect, not the
+    // instruction or the descriptor.  The fp32 record is a single cache line: there is no second line request to save.)
     x0 = ba_bufload(r, off, (const float *)nullptr);
     x1 = ba_bufload(r, off + 4, (const float *)nullptr);
     x2 = ba_bufload(r, off + 8, (const float *)nullptr);

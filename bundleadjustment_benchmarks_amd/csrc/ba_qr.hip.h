@@ -153,7 +153,10 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 // Scalars of a reflector.  float: the hardware square root and reciprocal (1 ulp) with one Newton step on the reciprocal -- the IEEE
 // sequences the compiler emits for `sqrtf` and `/` are ~40 instructions on the critical path of EVERY reflector step; a reflector's
 // beta and tau only have to be consistent with each other to working precision.  double: IEEE (the parity tests run in fp64).
-__device__ __forceinline__ float ba_qr_sqrt(float x) { return sqrtf(x); }
+// (BA_QR_HW_SQRT=1, diagnostic: the bare v_sqrt_f32 for beta -- round 3 saw config 3 accept no step with it; round 4's look at
+// that is in profiles/EXPERIMENTS.md 6.3)
+__device__ int ba_qr_hw_sqrt_flag = 0;
+__device__ __forceinline__ float ba_qr_sqrt(float x) { return ba_qr_hw_sqrt_flag ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
 __device__ __forceinline__ double ba_qr_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float ba_qr_rcp(float x)
 {
@@ -212,10 +215,17 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
         const T alpha = ba_readlane_dyn(a[0][pos], j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
         T tj = 0, sc = 0, beta = alpha;
         if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-            beta = ba_qr_sqrt(alpha * alpha + x2);
-            if (alpha > (T)0) beta = -beta;
-            tj = (beta - alpha) * ba_qr_rcp(beta);
-            sc = ba_qr_rcp(alpha - beta);
+            const T nb = ba_qr_sqrt(alpha * alpha + x2);
+            // nb == 0 with x2 != 0: the squared norm is a DENORMAL (config 3, fp32: a k1 column of a chunk that only holds entries of
+            // ~1e-21 -- squares of ~1e-42) and the square root flushed it.  sqrtf does not (a denormal's root is a normal number), the
+            // bare v_sqrt_f32 does: beta = 0, tau = 0 * inf = NaN, and every later column of the panel is NaN -- round 3's "no LM step
+            // accepted" with the hardware square root (profiles/EXPERIMENTS.md 6.3).  Such a column is zero to working precision:
+            // identity reflector, like x2 == 0.
+            if (nb != (T)0) {
+                beta = alpha > (T)0 ? -nb : nb;
+                tj = (beta - alpha) * ba_qr_rcp(beta);
+                sc = ba_qr_rcp(alpha - beta);
+            }
         }
         if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
         // the hand-over first (the others wait for it), then the column's way to memory: a masked-out element goes to a scratch word

@@ -378,6 +378,10 @@ template <typename T> struct Solver final : SolverBase {
         if ((rc = d_lm.alloc(1))) return rc;
         if ((rc = d_pperm.upload(std::vector<int>(M1, 0 | (1 << 2) | (2 << 4))))) return rc; // identity (CHOLESKY never pivots)
         if (kind == BA_QRKIT || kind == BA_QRSPQR) {
+            if (const char *ev = getenv("BA_QR_HW_SQRT")) { // diagnostic switch (ba_qr.hip.h: ba_qr_sqrt)
+                const int on = atoi(ev) != 0;
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_hw_sqrt_flag), &on, sizeof(int)));
+            }
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
             for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
                 for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
@@ -1000,6 +1004,16 @@ template <typename T> struct Solver final : SolverBase {
             for (int j = 0; j < Ml; j++)
                 for (int q = 0; q < 3; q++) out[3 * (size_t)j + q] = h[(size_t)q * Ml + j];
             for (int c = 0; c < D; c++) out[3 * (size_t)Ml + c] = h2[c];
+            return BA_OK;
+        }
+        case 11: { // diagnostic (QRKIT / QRSPQR, single shard, behind a step): the diagonal of R of the dense QR of J2bot (= the betas of the top TSQR level)
+            if (!dense_qr() || n != (size_t)D || !d_qA.p) return BA_ERR_ARG;
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<T> col(1);
+            for (int c = 0; c < D; c++) {
+                HIPCHK(hipMemcpy(col.data(), d_qA.p + (size_t)c * q_lda + c, sizeof(T), hipMemcpyDeviceToHost));
+                out[c] = (double)col[0];
+            }
             return BA_OK;
         }
         case BA_GET_CAMS:
