@@ -777,7 +777,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__restrict__ obs_pt, const int *__restrict__ pt_ptr,
                                                     const T *__restrict__ lam, const T *__restrict__ rec0, const T *__restrict__ tri0,
                                                     const T *__restrict__ tvec0, T *__restrict__ rec, T *__restrict__ dinv,
-                                                    T *__restrict__ tvec, T *__restrict__ tri)
+                                                    T *__restrict__ tvec, T *__restrict__ tri,
+                                                    T *__restrict__ mQl = nullptr /* [Ml][9]: the lambda rows of the block's thin Q */,
+                                                    T *__restrict__ mQR = nullptr /* [Ml][9]: its R1 rows */)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= K) return;
@@ -823,6 +825,12 @@ __global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__
         for (int c = 0; c < 3; c++) { dinv[(size_t)c * Ml + j] = 1; tvec[(size_t)c * Ml + j] = t[c]; }
         tri[j] = Rt[0][0]; tri[(size_t)Ml + j] = Rt[0][1]; tri[2 * (size_t)Ml + j] = Rt[0][2];
         tri[3 * (size_t)Ml + j] = Rt[1][1]; tri[4 * (size_t)Ml + j] = Rt[1][2]; tri[5 * (size_t)Ml + j] = Rt[2][2];
+        if (mQl) {
+#pragma unroll
+            for (int h = 0; h < 3; h++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { mQl[9 * (size_t)j + 3 * h + c] = Ql[h][c]; mQR[9 * (size_t)j + 3 * h + c] = QR[h][c]; }
+        }
     }
     const T *z = rec0 + (size_t)i * BA_REC;
     T *o = rec + (size_t)i * BA_REC;
@@ -834,6 +842,104 @@ __global__ __launch_bounds__(256) void k_more_trial(int K, int Ml, const int *__
         o[3 * c] = z0; o[3 * c + 1] = z1; o[3 * c + 2] = z2;
     }
     o[BA_REC_DINV] = 1; o[BA_REC_DINV + 1] = 1; o[BA_REC_DINV + 2] = 1;
+}
+
+// MOREQR, QR only (round 4; BacktrackLevMarqMore.h:297-345): what the per-point QRs of [sqrt(lambda) I3 ; R1_j] leave for the camera
+// columns, written densely for the Householder QR of ba_qr.hip.h -- the inner counterpart of J2bot (k_qrkit_build):
+//   rows 6 j .. 6 j + 5 (point j): (I - Q Q^T) [0 ; R12_j] with the block's thin Q = [Ql ; QR] (6 x 3), i.e. for the observation ia of
+//     camera a:  lambda rows  -Ql Z_ia^T,  R1 rows  Z0_ia^T - QR Z_ia^T   (Z0 = R12^T of the outer factorisation, Z = Z0 QR: both 9 x 3 records);
+//     right-hand side column D: (I - Q Q^T) [0 ; -q1_j] = [-Ql t ; (-q1) - QR t],  t = QR^T (-q1)  (tvec0 = -q1, tvec = t);
+//   rows 6 M ...: R22 (D x D, upper triangle) and the head of Q^T (-qtb2) from the outer dense QR, then sqrt(lambda) I_D (k_more_tail).
+// One thread per observation; the first observation of a point also writes its right-hand side rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_more_build(int K, int Ml, int D, const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                                    const int *__restrict__ pt_ptr, const T *__restrict__ rec0, const T *__restrict__ rec,
+                                                    const T *__restrict__ mQl, const T *__restrict__ mQR, const T *__restrict__ tvec0,
+                                                    const T *__restrict__ tvec, T *__restrict__ A, size_t lda)
+{
+    const int ia = blockIdx.x * 256 + threadIdx.x;
+    if (ia >= K) return;
+    const int j = obs_pt[ia], a = obs_cam[ia];
+    const size_t r0 = 6 * (size_t)j;
+    T Ql[9], QR[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) { Ql[q] = mQl[9 * (size_t)j + q]; QR[q] = mQR[9 * (size_t)j + q]; }
+    const T *z0 = rec0 + (size_t)ia * BA_REC, *z = rec + (size_t)ia * BA_REC;
+    T *colbase = A + (size_t)(9 * a) * lda + r0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const T z_0 = z[3 * c], z_1 = z[3 * c + 1], z_2 = z[3 * c + 2];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            colbase[(size_t)c * lda + rr] = -(Ql[3 * rr] * z_0 + Ql[3 * rr + 1] * z_1 + Ql[3 * rr + 2] * z_2);
+            colbase[(size_t)c * lda + 3 + rr] = z0[3 * c + rr] - (QR[3 * rr] * z_0 + QR[3 * rr + 1] * z_1 + QR[3 * rr + 2] * z_2);
+        }
+    }
+    if (ia == pt_ptr[j]) {
+        const size_t M = (size_t)Ml;
+        const T m0 = tvec0[j], m1 = tvec0[M + j], m2 = tvec0[2 * M + j], t0 = tvec[j], t1 = tvec[M + j], t2 = tvec[2 * M + j];
+        const T mq[3] = {m0, m1, m2};
+        T *rhs = A + (size_t)D * lda + r0;
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            rhs[rr] = -(Ql[3 * rr] * t0 + Ql[3 * rr + 1] * t1 + Ql[3 * rr + 2] * t2);
+            rhs[3 + rr] = mq[rr] - (QR[3 * rr] * t0 + QR[3 * rr + 1] * t1 + QR[3 * rr + 2] * t2);
+        }
+    }
+}
+// the tail of that matrix (shard 0 only): R22 | c2 from the outer factorisation (R22buf: D x (D + 1), column-major ld D), sqrt(lambda) I_D
+template <typename T>
+__global__ __launch_bounds__(256) void k_more_tail(int Ml, int D, const T *__restrict__ R22buf, const T *__restrict__ lam, T *__restrict__ A, size_t lda, T dbg_scale = (T)1)
+{
+    const int c = blockIdx.x; // column 0 .. D (D = the right-hand side)
+    size_t rR = 6 * (size_t)Ml, rL = rR + (size_t)D;
+    if (dbg_scale < (T)0) { dbg_scale = -dbg_scale; rL = rR; rR = rL + (size_t)D; } // (experiment: the sqrt(lambda) rows in front of R22)
+    const int top = c < D ? c : D - 1;
+    for (int i = threadIdx.x; i <= top; i += 256) A[(size_t)c * lda + rR + i] = R22buf[(size_t)c * D + i];
+    if (c < D && threadIdx.x == 0) A[(size_t)c * lda + rL + c] = tsqrt(*lam) * dbg_scale;
+}
+// R22 and the head of the transformed right-hand side out of a factored matrix (its first D rows), conditional on the step control
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_r22(int D, const T *__restrict__ A, size_t lda, T *__restrict__ R22buf, const int *__restrict__ go)
+{
+    if (go && *go == 0) return;
+    const int c = blockIdx.x;
+    const int top = c < D ? c : D - 1;
+    for (int i = threadIdx.x; i < D; i += 256) R22buf[(size_t)c * D + i] = i <= top ? A[(size_t)c * lda + i] : (T)0;
+}
+
+// diagnostic (BA_DBG_ATB): out[c] = sum_r A[r][c] A[r][D] over the first `rows` rows -- A^T b of a built matrix, before it is factored
+template <typename T>
+__global__ __launch_bounds__(256) void k_dbg_atb(int rows, int D, const T *__restrict__ A, size_t lda, T *__restrict__ out)
+{
+    __shared__ T red[4];
+    const int c = blockIdx.x;
+    T a = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) a += A[(size_t)c * lda + r] * A[(size_t)D * lda + r];
+    a = block_reduce<T, false>(a, red);
+    if (threadIdx.x == 0) out[c] = a;
+}
+
+// diagnostic (BA_DBG_QRCHECK): the self-check of a least-squares solve  min || A y - b ||  on a copy of the matrix kept from before its
+// factorisation: r = b - A y (thread per row), then out[c] = A(:, c)^T r and out[D + c] = A(:, c)^T b  (k_dbg_atb's layout, two passes)
+template <typename T>
+__global__ __launch_bounds__(256) void k_dbg_resid(int rows, int D, const T *__restrict__ A, size_t lda, const T *__restrict__ y, T *__restrict__ r)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    T a = A[(size_t)D * lda + i];
+    for (int c = 0; c < D; c++) a -= A[(size_t)c * lda + i] * y[c];
+    r[i] = a;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_dbg_atv(int rows, int D, const T *__restrict__ A, size_t lda, const T *__restrict__ v, T *__restrict__ out)
+{
+    __shared__ T red[4];
+    const int c = blockIdx.x;
+    T a = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) a += A[(size_t)c * lda + r] * v[r];
+    a = block_reduce<T, false>(a, red);
+    if (threadIdx.x == 0) out[c] = a;
 }
 
 // ---- K5: Schur complement / reduced camera matrix, pair-owner form -------------------------------------------

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
                                                      const T *__restrict__ r /* SoA [2][K] */, const T *__restrict__ rec,
                                                      const T *__restrict__ q1obs /* [K][6] */, const T *__restrict__ q1lam /* [Ml][9] */,
                                                      const T *__restrict__ tvec /* SoA [3][Ml] = -q1 */, const T *__restrict__ lam,
-                                                     T *__restrict__ A, size_t lda, int cam_rows /* sharded: the camera rows belong to shard 0 */)
+                                                     T *__restrict__ A, size_t lda, int cam_rows /* sharded: the camera rows belong to shard 0 */,
+                                                     const int *__restrict__ go = nullptr)
 {
+    if (go && *go == 0) return; // (uniform)
     const int ia = blockIdx.x * 256 + threadIdx.x;
     if (cam_rows && ia < D) A[(size_t)ia * lda + 2 * (size_t)K + 3 * (size_t)Ml + ia] = sqrt(*lam); // camera rows: sqrt(lambda) I_D, zero rhs
     if (ia >= K) return;
@@ -156,6 +158,7 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 // (BA_QR_HW_SQRT=1, diagnostic: the bare v_sqrt_f32 for beta -- round 3 saw config 3 accept no step with it; round 4's look at
 // that is in profiles/EXPERIMENTS.md 6.3)
 __device__ int ba_qr_hw_sqrt_flag = 0;
+__device__ int ba_qr_dbg_flag = 0; // diagnostic bits (BA_QR_DBG): 1 = full barrier in the step loop, 2 = agent acquire before the T factor re-reads V
 __device__ __forceinline__ float ba_qr_sqrt(float x) { return ba_qr_hw_sqrt_flag ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
 __device__ __forceinline__ double ba_qr_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float ba_qr_rcp(float x)
@@ -168,8 +171,10 @@ __device__ __forceinline__ double ba_qr_rcp(double x) { return 1.0 / x; }
 #define BA_QR_CWV 8 /* waves of a k_qr_chunk workgroup (two per SIMD: one's reductions and LDS round trips hide behind the other's FMAs) */
 template <typename T, int NSB>
 __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                  T *__restrict__ Tout /* [chunks][32 * 32] */, int nch)
+                                                  T *__restrict__ Tout /* [chunks][32 * 32] */, int nch,
+                                                  const int *__restrict__ go = nullptr /* device-side LM control: *go == 0 -> nothing to do (MOREQR's outer QR) */)
 {
+    if (go && *go == 0) return; // (uniform)
     constexpr int NW = BA_QR_CWV, CH = BA_QR_PB * NSB, RPL = CH / 64, CW = BA_QR_PB / NW, RTW = CH / (16 * NW);
     static_assert(RTW >= 1, "a wave owns at least one row tile of the Gram product");
     __shared__ T vs[2][CH];
@@ -278,7 +283,8 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             if (jw == wv) form(jq, j);     // (wave-uniform) this wave's column jq is column j
             // LDS-only barrier: the hand-over goes through LDS; __syncthreads() would also wait for the owner's global stores of the
             // retired column
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ba_qr_dbg_flag & 1) __syncthreads();
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef BA_QR_STAMP
             long long t_exit = 0;
             if (nch == 1) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); t_exit = (long long)t_; if (threadIdx.x == 0) ba_qr_stamp[j] = t_exit; }
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #endif
     // ---- T factor.  The retired columns are in memory (written by different waves of this workgroup: visible behind the barrier).
     __syncthreads();
+    if (ba_qr_dbg_flag & 2) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
     {
         typedef typename ba_acc<T>::type acc_t;
         const int i = lane & 15, q = lane >> 4;
@@ -403,8 +410,10 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #define BA_QR_AW 8 /* waves of a k_qr_apply workgroup */
 template <typename T, int NSB>
 __global__ __launch_bounds__(64 * BA_QR_AW) void k_qr_apply(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
-                                                           const T *__restrict__ Tg, int col0, int col1, int nch, int nct)
+                                                           const T *__restrict__ Tg, int col0, int col1, int nch, int nct,
+                                                           const int *__restrict__ go = nullptr)
 {
+    if (go && *go == 0) return; // (uniform)
     constexpr int CH = BA_QR_PB * NSB, RTW = CH / (16 * BA_QR_AW), PB = BA_QR_PB;
     static_assert(RTW >= 1 && PB == 32, "a wave owns at least one row tile; the tile helpers are written for 32 columns");
     typedef typename ba_acc<T>::type acc_t;
@@ -638,6 +647,7 @@ template <typename T> inline void ba_qr_backsolve(hipStream_t st, const T *A, si
 struct ba_qr_side {
     hipStream_t st2 = nullptr, st3 = nullptr;
     hipEvent_t ev_chunk = nullptr, ev_apply = nullptr, ev_next = nullptr; // chunk done (st) | rest updated (st2) | next panel updated (st3)
+    const int *go = nullptr; // every kernel of the factorisation returns at once while *go == 0 (MOREQR's outer QR behind a rejected trial)
     bool two() const { return st2 && ev_chunk && ev_apply; }
     bool lookahead() const { return two() && st3 && ev_next; }
 };
@@ -655,9 +665,9 @@ inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *
         // (8 x ceil(nch / 8) x nct workgroups: chunk g's strips sit at blockIdx % 8 == g % 8)
         const dim3 ga((unsigned)(8ll * ((nch + 7) / 8) * nct));
         if (level == 1)
-            hipLaunchKernelGGL((k_qr_apply<T, NSB1>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct);
+            hipLaunchKernelGGL((k_qr_apply<T, NSB1>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct, sd.go);
         else
-            hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct);
+            hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct, sd.go);
     };
     for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
         const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
@@ -675,8 +685,8 @@ inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *
             const int fan = level == 1 ? NSB1 : NSBU;
             const int nch = (nsb + fan - 1) / fan;
             T *tl = tau + (size_t)(level - 1) * tau_level_stride;
-            if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
-            else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch);
+            if (level == 1) hipLaunchKernelGGL((k_qr_chunk<T, NSB1>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch, sd.go);
+            else hipLaunchKernelGGL((k_qr_chunk<T, NSBU>), dim3(nch), dim3(64 * BA_QR_CWV), 0, st, A, lda, c0, bw, c0, level, stride, nsb, tl, nch, sd.go);
             if (col0 < col1) {
                 if (two) (void)hipEventRecord(sd.ev_chunk, st);
                 if (la) {

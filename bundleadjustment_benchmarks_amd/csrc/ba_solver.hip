@@ -151,7 +151,19 @@ template <typename T> struct Solver final : SolverBase {
     int q_rows = 0;
     // QRKIT / QRSPQR always run the dense QR of J2bot -- sharded too (distributed TSQR: launch_qr_stack), never QRCHOL's normal
     // equations under another name
-    bool dense_qr() const { return kind == BA_QRKIT || kind == BA_QRSPQR; }
+    // (round 4) ... and so can MOREQR (BA_MOREQR_QR=1, read at solver creation): its right block as the dense QR of [rows left by the
+    // per-point QRs ; R22 ; sqrt(lambda) I] (BacktrackLevMarqMore.h:297-345), R22 from one dense QR of J2bot(lambda = 0) per outer
+    // iteration (:288) -- no S, no LDL^T, sharded through the same TSQR stack.  NOT the default yet: round 4's self-check of the dense QR
+    // kernels (BA_DBG_QRCHECK, scripts/diag_qrcheck.py) found that ~8 % of their solves lose accuracy (normal-equation residual 1e-9 ... 4e-5
+    // instead of 1e-13; QRKIT's too), which MOREQR's per-trial bounds against the quad referee do not forgive; the default keeps forming
+    // S = (Jc'Jc + lambda I) - sum Z Z' and factoring it by LDL^T.
+    bool more_qr_on = false;
+    bool dense_qr() const { return kind == BA_QRKIT || kind == BA_QRSPQR || more_qr(); }
+    bool more_qr() const { return kind == BA_MOREQR && more_qr_on; }
+    DevBuf<T> d_dbg; // diagnostic buffer (BA_DBG_ATB)
+    DevBuf<T> d_mQl, d_mQR, d_R22; // MOREQR: the inner point blocks' thin Q (lambda rows, R1 rows: [Ml][9] each); R22 | c2 of the outer QR, D x (D + 1)
+    int outer_rows() const { return 2 * Kl + 3 * Ml + D; }               // J2bot (QRKIT / QRSPQR per trial; MOREQR per outer iteration, lambda = 0)
+    int inner_rows() const { return more_qr() ? 6 * Ml + 2 * D : outer_rows(); } // the matrix a TRIAL factors
     DevBuf<T> d_qB; // sharded: the stack of the shards' R factors (+ rhs column), behind it g_c and the energy (one all-reduce)
     size_t qb_ld() const { return (size_t)world * D + 64; }
     size_t qb_nmat() const { return qb_ld() * (size_t)(D + 1); }
@@ -207,6 +219,7 @@ template <typename T> struct Solver final : SolverBase {
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
     {
         kind = k; rank = rk; world = wd;
+        more_qr_on = getenv("BA_MOREQR_QR") != nullptr && atoi(getenv("BA_MOREQR_QR")) != 0;
         int rc = ba_build_structure(p, rk, wd, BA_CHUNK, 32 /* lanes of a k_cam_gram group */, &sx);
         if (rc) return rc;
         N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
@@ -377,7 +390,11 @@ template <typename T> struct Solver final : SolverBase {
         if (kind == BA_MOREQR) { AL(d_rec0, (size_t)BA_REC * K1); AL(d_dinv0, 3 * M1); AL(d_tvec0, 3 * M1); AL(d_tri0, 6 * M1); }
         if ((rc = d_lm.alloc(1))) return rc;
         if ((rc = d_pperm.upload(std::vector<int>(M1, 0 | (1 << 2) | (2 << 4))))) return rc; // identity (CHOLESKY never pivots)
-        if (kind == BA_QRKIT || kind == BA_QRSPQR) {
+        if (dense_qr()) {
+            if (const char *ev = getenv("BA_QR_DBG")) { // diagnostic bits (ba_qr.hip.h: ba_qr_dbg_flag)
+                const int bits = atoi(ev);
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_dbg_flag), &bits, sizeof(int)));
+            }
             if (const char *ev = getenv("BA_QR_HW_SQRT")) { // diagnostic switch (ba_qr.hip.h: ba_qr_sqrt)
                 const int on = atoi(ev) != 0;
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_hw_sqrt_flag), &on, sizeof(int)));
@@ -387,7 +404,8 @@ template <typename T> struct Solver final : SolverBase {
                 for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
                     for (int i2 = sx.pt_ptr[j]; i2 < i; i2++)
                         if (sx.obs_cam[i] == sx.obs_cam[i2]) return BA_ERR_ARG;
-            q_rows = 2 * Kl + 3 * Ml + D;
+            q_rows = std::max(outer_rows(), inner_rows());
+            if (more_qr()) { AL(d_mQl, 9 * M1); AL(d_mQR, 9 * M1); AL(d_R22, (size_t)D * (D + 1)); AL(d_dbg, (size_t)D); }
             if (!getenv("BA_QR_ONE_STREAM")) {
                 HIPCHK(hipStreamCreateWithFlags(&st_qr, hipStreamNonBlocking));
                 // (look-ahead on a third stream: measured, not the default -- 2.27 - 2.34 against 2.38 ms stand-alone, but 375 against
@@ -524,6 +542,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         if ((rc = linearize_enqueue(diag_max != nullptr, nullptr))) return rc;
+        if (more_qr() && (rc = more_outer_finish(nullptr))) return rc;
         if (sharded()) { // the kernels left this shard's part in SC_ELOC (it also rides on the next trial's packed all-reduce)
             HIPCHK(hipMemcpyAsync(d_scal.p + SC_ENERGY, d_scal.p + SC_ELOC, sizeof(T), hipMemcpyDeviceToDevice, st));
             if ((rc = allreduce(d_scal.p + SC_ENERGY, 1, 0))) return rc;
@@ -556,8 +575,10 @@ template <typename T> struct Solver final : SolverBase {
         const bool fz = fuse && go != nullptr && !want_dmax;
         launch_eval(true, go ? 1 : 0, go, go != nullptr, fz);
         launch_grad(go, tail ? &jobs.j[0] : nullptr, !fz);
-        if (kind == BA_MOREQR) // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291)
-            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go);
+        if (kind == BA_MOREQR) { // m_solver.compute(J) + Q^T r, once per outer iteration (BacktrackLevMarqMore.h:288-291): the point blocks ...
+            launch_elim_qr(d_scal.p + SC_ZERO, d_rec0.p, d_dinv0.p, d_tvec0.p, d_tri0.p, go, /*thin Q for J2bot*/ more_qr());
+            if (more_qr() && (rc = launch_more_outer(go))) return rc; // ... and the dense QR of J2bot(lambda = 0); its part 2 follows where a collective may stand
+        }
         if (tail) { have_step = false; return BA_OK; }
         if (want_dmax) {
             // max diag(J^T J): point part per shard, camera part from the (summed over shards) diagonal of J_c^T J_c
@@ -582,7 +603,7 @@ template <typename T> struct Solver final : SolverBase {
         } else if (kind == BA_MOREQR) {
             if (Kl > 0) // BacktrackLevMarqMore.h:297-345, the per-trial QR of [R ; sqrt(lambda) I]
                 hipLaunchKernelGGL((k_more_trial<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, d_obs_pt.p, d_pt_ptr.p, d_scal.p + SC_LAMBDA,
-                                   d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p);
+                                   d_rec0.p, d_tri0.p, d_tvec0.p, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p, d_mQl.p, d_mQR.p);
         } else {
             launch_elim_qr(d_scal.p + SC_LAMBDA, d_rec.p, d_dinv.p, d_tvec.p, d_tri.p, nullptr, dense_qr());
         }
@@ -720,14 +741,76 @@ template <typename T> struct Solver final : SolverBase {
     // QRKIT's right block (BAFunctor.h:101): J2bot built densely, Householder QR (ba_qr.hip.h), dx_c from R y = -Q^T qtb2
     void launch_qrkit_build()
     {
+        if (more_qr()) { launch_more_build(); return; }
         (void)hipMemsetAsync(d_qA.p, 0, sizeof(T) * d_qA.n, st);
         const int nthr = std::max(Kl, D);
         hipLaunchKernelGGL((k_qrkit_build<T>), dim3((nthr + 255) / 256), dim3(256), 0, st, Kl, Ml, D, d_obs_cam.p, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_r.p,
                            d_rec.p, d_q1obs.p, d_q1lam.p, d_tvec.p, d_scal.p + SC_LAMBDA, d_qA.p, q_lda, rank == 0 ? 1 : 0);
     }
+    // MOREQR per trial (behind k_more_trial): the dense matrix the inner QR factors (k_more_build, k_more_tail)
+    void launch_more_build()
+    {
+        (void)hipMemsetAsync(d_qA.p, 0, sizeof(T) * d_qA.n, st);
+        if (Kl > 0)
+            hipLaunchKernelGGL((k_more_build<T>), dim3(gK), dim3(256), 0, st, Kl, Ml, D, d_obs_cam.p, d_obs_pt.p, d_pt_ptr.p, d_rec0.p, d_rec.p, d_mQl.p, d_mQR.p,
+                               d_tvec0.p, d_tvec.p, d_qA.p, q_lda);
+        static const double dbg = getenv("BA_DBG_TAIL") ? (atof(getenv("BA_DBG_TAIL")) == -1.0 ? -1.0 : 1.0 + atof(getenv("BA_DBG_TAIL"))) : 1.0;
+        if (rank == 0) hipLaunchKernelGGL((k_more_tail<T>), dim3(D + 1), dim3(256), 0, st, Ml, D, d_R22.p, d_scal.p + SC_LAMBDA, d_qA.p, q_lda, (T)dbg);
+        static const bool dbg_atb = getenv("BA_DBG_ATB") != nullptr;
+        if (dbg_atb) { // A^T b of the matrix as built, into the spare half of the step vector (getter 13)
+            hipLaunchKernelGGL((k_dbg_atb<T>), dim3(D), dim3(256), 0, st, inner_rows(), D, (const T *)d_qA.p, q_lda, d_dbg.p);
+        }
+    }
+    // MOREQR per outer iteration (behind k_elim_qr with lambda = 0; BacktrackLevMarqMore.h:288-291): the dense QR of J2bot(lambda = 0).
+    // Part 1 (capturable): build + this shard's factorisation (+ sharded: its R | c2 into the zeroed stack).  Part 2: sharded -- the
+    // all-reduce of the stack and its QR (distributed TSQR, like QRKIT's trial) --, then R22 | c2 out of the factored matrix.  Every
+    // kernel is conditional on the step control (go): behind a rejected trial R22 stays what it was.
+    int launch_more_outer(const int *go)
+    {
+        (void)hipMemsetAsync(d_qA.p, 0, sizeof(T) * d_qA.n, st);
+        if (Kl > 0)
+            hipLaunchKernelGGL((k_qrkit_build<T>), dim3((std::max(Kl, D) + 255) / 256), dim3(256), 0, st, Kl, Ml, D, d_obs_cam.p, d_obs_pt.p, d_pt_ptr.p, d_Jc.p, d_r.p,
+                               d_rec0.p, d_q1obs.p, d_q1lam.p, d_tvec0.p, d_scal.p + SC_ZERO, d_qA.p, q_lda, 0, go);
+        ba_qr_side sd = qr_side();
+        sd.go = go;
+        ba_qr_factor<T>(st, d_qA.p, q_lda, outer_rows(), D, d_qtau.p, q_tau_stride, sd);
+        if (sharded()) {
+            int rc;
+            if (!d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
+            HIPCHK(hipMemsetAsync(d_qB.p, 0, sizeof(T) * qb_nmat(), st));
+            hipLaunchKernelGGL((k_qr_stack_pack<T>), dim3(D + 2), dim3(256), 0, st, (const T *)d_qA.p, q_lda, D, rank, d_qB.p, qb_ld(), qb_nmat(), (const T *)d_gc.p,
+                               (const T *)d_scal.p, (int)SC_ELOC);
+        }
+        return BA_OK;
+    }
+    int more_outer_finish(const int *go)
+    {
+        if (sharded()) {
+            int rc;
+            if ((rc = allreduce(d_qB.p, qb_count(), 0))) return rc;
+            ba_qr_side sd = qr_side();
+            sd.go = go;
+            ba_qr_factor<T>(st, d_qB.p, qb_ld(), world * D, D, d_qtau.p, q_tau_stride, sd);
+            hipLaunchKernelGGL((k_copy_r22<T>), dim3(D + 1), dim3(256), 0, st, D, (const T *)d_qB.p, qb_ld(), d_R22.p, go);
+        } else
+            hipLaunchKernelGGL((k_copy_r22<T>), dim3(D + 1), dim3(256), 0, st, D, (const T *)d_qA.p, q_lda, d_R22.p, go);
+        return BA_OK;
+    }
+    DevBuf<T> d_qAcopy, d_dbgr, d_dbg2; // BA_DBG_QRCHECK
     void launch_qrkit_solve()
     {
-        ba_qr_solve<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, d_dxc.p, qr_side());
+        static const bool chk = getenv("BA_DBG_QRCHECK") != nullptr;
+        if (chk) {
+            if (!d_qAcopy.p) { (void)d_qAcopy.alloc(d_qA.n); (void)d_dbgr.alloc(q_lda); (void)d_dbg2.alloc((size_t)2 * D); }
+            (void)hipMemcpyAsync(d_qAcopy.p, d_qA.p, sizeof(T) * d_qA.n, hipMemcpyDeviceToDevice, st);
+        }
+        ba_qr_solve<T>(st, d_qA.p, q_lda, inner_rows(), D, d_qtau.p, q_tau_stride, d_dxc.p, qr_side());
+        if (chk) {
+            const int rows = inner_rows();
+            hipLaunchKernelGGL((k_dbg_resid<T>), dim3((rows + 255) / 256), dim3(256), 0, st, rows, D, (const T *)d_qAcopy.p, q_lda, (const T *)d_dxc.p, d_dbgr.p);
+            hipLaunchKernelGGL((k_dbg_atv<T>), dim3(D), dim3(256), 0, st, rows, D, (const T *)d_qAcopy.p, q_lda, (const T *)d_dbgr.p, d_dbg2.p);
+            hipLaunchKernelGGL((k_dbg_atv<T>), dim3(D), dim3(256), 0, st, rows, D, (const T *)d_qAcopy.p, q_lda, (const T *)(d_qAcopy.p + (size_t)D * q_lda), d_dbg2.p + D);
+        }
         (void)hipMemcpyAsync(d_gcg.p, d_gc.p, sizeof(T) * (size_t)D, hipMemcpyDeviceToDevice, st); // the camera gradient of the rho denominator
     }
     // Sharded QRKIT (distributed TSQR, ba_qr.hip.h): the QR of this shard's rows, its R + rhs head into the zeroed stack ...
@@ -735,7 +818,7 @@ template <typename T> struct Solver final : SolverBase {
     {
         int rc;
         if (!d_qB.p && (rc = d_qB.alloc(qb_count()))) return rc;
-        ba_qr_factor<T>(st, d_qA.p, q_lda, q_rows, D, d_qtau.p, q_tau_stride, qr_side());
+        ba_qr_factor<T>(st, d_qA.p, q_lda, inner_rows(), D, d_qtau.p, q_tau_stride, qr_side());
         HIPCHK(hipMemsetAsync(d_qB.p, 0, sizeof(T) * qb_nmat(), st));
         hipLaunchKernelGGL((k_qr_stack_pack<T>), dim3(D + 2), dim3(256), 0, st, (const T *)d_qA.p, q_lda, D, rank, d_qB.p, qb_ld(), qb_nmat(), (const T *)d_gc.p,
                            (const T *)d_scal.p, (int)SC_ELOC);
@@ -852,7 +935,9 @@ template <typename T> struct Solver final : SolverBase {
     {
         ba_lm_slots sl{SC_ENERGY, SC_ETEST, SC_RHO_P, SC_RHO_C, SC_DN_P, SC_DN_C, SC_LAMBDA, SC_ERR, SC_GUARD, world};
         hipLaunchKernelGGL((k_lm_control<T>), dim3(1), dim3(256 * BA_LM_JOBS), 0, st, d_scal.p, d_lm.p, d_log, sl, test_energy_jobs(), ctl_reduces() ? 3 : 0);
-        return linearize_enqueue(false, &d_lm.p->go); // (x = xTest happens inside its first kernel)
+        int rc = linearize_enqueue(false, &d_lm.p->go); // (x = xTest happens inside its first kernel)
+        if (!rc && more_qr() && !sharded()) rc = more_outer_finish(&d_lm.p->go); // (sharded: behind the segment, it holds an all-reduce -- enqueue_trial)
+        return rc;
     }
 
     // m_solver.compute .. dx; xTest = x (+) dx; m_functor(xTest); rhoScale (BacktrackLevMarqQRChol.h:291-375): the step-level
@@ -1016,6 +1101,32 @@ template <typename T> struct Solver final : SolverBase {
             }
             return BA_OK;
         }
+        case 14: { // diagnostic (BA_DBG_QRCHECK): [A^T (b - A y) | A^T b] of the last dense least-squares solve, 2 D values
+            if (!dense_qr() || n != (size_t)2 * D || !d_dbg2.p) return BA_ERR_ARG;
+            std::vector<T> hh;
+            int rcg;
+            if ((rcg = dl(d_dbg2.p, (size_t)2 * D, hh))) return rcg;
+            for (int c = 0; c < 2 * D; c++) out[c] = (double)hh[c];
+            return BA_OK;
+        }
+        case 13: { // diagnostic (BA_DBG_ATB): A^T b of MOREQR's inner matrix as built
+            if (!more_qr() || n != (size_t)D) return BA_ERR_ARG;
+            std::vector<T> hh;
+            int rcg;
+            if ((rcg = dl(d_dbg.p, (size_t)D, hh))) return rcg;
+            for (int c = 0; c < D; c++) out[c] = (double)hh[c];
+            return BA_OK;
+        }
+        case 12: { // diagnostic: the first D rows of the factored matrix, all D + 1 columns (R | the head of Q^T rhs), column-major D x (D + 1)
+            if (!dense_qr() || n != (size_t)D * (D + 1) || !d_qA.p) return BA_ERR_ARG;
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<T> col((size_t)D);
+            for (int c = 0; c <= D; c++) {
+                HIPCHK(hipMemcpy(col.data(), d_qA.p + (size_t)c * q_lda, sizeof(T) * (size_t)D, hipMemcpyDeviceToHost));
+                for (int i = 0; i < D; i++) out[(size_t)c * D + i] = (c < D && i > c) ? 0.0 : (double)col[i];
+            }
+            return BA_OK;
+        }
         case BA_GET_CAMS:
         case BA_GET_CAMS_TEST: {
             if (n != 15 * (size_t)N) return BA_ERR_ARG;
@@ -1115,6 +1226,7 @@ template <typename T> struct Solver final : SolverBase {
         }
         HIPCHK(hipEventRecord(e.e[4], st));
         if ((rc = run_seg(&g_ctl, &Solver::launch_seg_ctl, graphs))) return rc;
+        if (more_qr() && (rc = more_outer_finish(&d_lm.p->go))) return rc; // MOREQR's outer R22: the shards' R factors meet in one more all-reduce
         HIPCHK(hipEventRecord(e.e[5], st));
         return BA_OK;
     }

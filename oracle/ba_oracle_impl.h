@@ -336,6 +336,67 @@ static void FN(dense_qr_solve)(int m, int n, S *A, S *b, S *x)
     }
 }
 
+/* Householder QR of a TALL m x n matrix (column-major, ld m) with the right-hand side b riding along, by row chunks (a TSQR tree of
+ * depth two): every chunk of CHK rows is factored by itself -- it stays in cache, the plain column loop above streams the whole
+ * matrix from memory once per reflector -- and the chunks' R factors (+ the heads of their Q^T b) are stacked and factored again.
+ * On exit R (n x n, upper triangle, column-major ld n) and c = the first n entries of Q^T b.  Used by MOREQR's two dense QRs
+ * (BacktrackLevMarqMore.h:288, :328); the QRKIT / QRSPQR symbols keep the plain loop (their committed fixtures hold its bits). */
+static int FN(dense_qr_factor_tsqr)(size_t m, int n, const S *A, const S *b, S *R, S *c)
+{
+    const size_t CHK = 2048;
+    const size_t nch = (m + CHK - 1) / CHK;
+    const size_t ms = nch * (size_t)n; /* rows of the stack */
+    S *T = (S *)malloc(sizeof(S) * CHK * (size_t)(n + 1));
+    S *St = (S *)calloc(ms * (size_t)(n + 1), sizeof(S));
+    if (!T || !St) { free(T); free(St); return -1; }
+    for (int pass = 0; pass < 2; pass++) {
+        const size_t rows_total = pass == 0 ? m : ms, chunks = pass == 0 ? nch : 1;
+        for (size_t g = 0; g < chunks; g++) {
+            const size_t r0 = pass == 0 ? g * CHK : 0, mr = pass == 0 ? (r0 + CHK <= m ? CHK : m - r0) : ms;
+            S *W = pass == 0 ? T : St; /* the stack is factored in place */
+            const size_t ldw = pass == 0 ? mr : ms;
+            if (pass == 0) {
+                for (int j = 0; j < n; j++)
+                    for (size_t i = 0; i < mr; i++) W[(size_t)j * ldw + i] = A[(size_t)j * m + r0 + i];
+                for (size_t i = 0; i < mr; i++) W[(size_t)n * ldw + i] = b[r0 + i];
+            }
+            const int kmax = (size_t)n < mr ? n : (int)mr;
+            for (int j = 0; j < kmax; j++) {
+                S *col = W + (size_t)j * ldw;
+                S xn = 0;
+                for (size_t i = j + 1; i < mr; i++) xn += col[i] * col[i];
+                const S alpha = col[j];
+                if (xn == 0) continue; /* H = I */
+                S beta = SQRT(alpha * alpha + xn);
+                if (alpha > 0) beta = -beta;
+                const S tau = (beta - alpha) / beta;
+                const S sc = (S)1.0 / (alpha - beta);
+                for (size_t i = j + 1; i < mr; i++) col[i] *= sc;
+                col[j] = beta;
+                for (int cc_ = j + 1; cc_ <= n; cc_++) {
+                    S *cc = W + (size_t)cc_ * ldw;
+                    S w = cc[j];
+                    for (size_t i = j + 1; i < mr; i++) w += col[i] * cc[i];
+                    w *= tau;
+                    cc[j] -= w;
+                    for (size_t i = j + 1; i < mr; i++) cc[i] -= col[i] * w;
+                }
+            }
+            if (pass == 0) { /* R and the head of Q^T b of this chunk into block g of the stack */
+                for (int j = 0; j <= n; j++)
+                    for (int i = 0; i < n && (size_t)i < mr; i++)
+                        if (j == n || i <= j) St[(size_t)j * ms + g * (size_t)n + i] = W[(size_t)j * ldw + i];
+            }
+        }
+        (void)rows_total;
+    }
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) R[(size_t)j * n + i] = i <= j ? St[(size_t)j * ms + i] : (S)0;
+    for (int i = 0; i < n; i++) c[i] = St[(size_t)n * ms + i];
+    free(T); free(St);
+    return 0;
+}
+
 /* Workspace of the per-point elimination shared by all three solver symbols:
  *   Z[i]    9x3 per observation (row-major): CHOLESKY  Z = A^T B L^-T     (W L^-T)
  *                                            QR        Z = R12_i^T = A^T Q1_i
@@ -519,18 +580,18 @@ typedef struct {
     int *perm; /* M x 3: column permutation of the outer factorisation */
 } FN(more_t);
 
-static void FN(more_outer)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, FN(more_t) * o)
+static void FN(more_outer)(int M, const int *pt_ptr, const S *Jc, const S *Jp, const S *fvec, FN(more_t) * o, S *Q1obs, S *Q1lam)
 {
     FN(elim_t) e;
     int K = pt_ptr[M];
     e.Z = o->R12T; e.tri = o->R1; e.t = o->mq1; e.perm = o->perm;
     e.dinv = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
     (void)K;
-    FN(elim_qr)(M, pt_ptr, Jc, Jp, fvec, (S)0, &e, NULL, NULL); /* lambda = 0: QR of [B;0] */
+    FN(elim_qr)(M, pt_ptr, Jc, Jp, fvec, (S)0, &e, Q1obs, Q1lam); /* lambda = 0: QR of [B;0] */
     free(e.dinv);
 }
 
-static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) * o, FN(elim_t) * e)
+static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) * o, FN(elim_t) * e, S *mQl /* M x 9 or NULL */, S *mQR /* M x 9 or NULL */)
 {
     const S sl = SQRT(lambda);
     for (int j = 0; j < M; j++) {
@@ -555,7 +616,7 @@ static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) 
                 for (int r = 3; r < 6; r++) W[c2][r] -= W[c][r] * w;
             }
         }
-        /* thin Q: lambda rows Ql (not needed), R1 rows QR[r][c] */
+        /* thin Q (6 x 3): lambda rows Ql[h][c], R1 rows QR[r][c] */
         S Ql[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, QR[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (int h = 2; h >= 0; h--)
             for (int c = 0; c < 3; c++) {
@@ -565,6 +626,9 @@ static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) 
                 Ql[h][c] -= w;
                 for (int r = 0; r < 3; r++) QR[r][c] -= W[h][3 + r] * w;
             }
+        if (mQl)
+            for (int h = 0; h < 3; h++)
+                for (int c = 0; c < 3; c++) { mQl[9 * (size_t)j + 3 * h + c] = Ql[h][c]; mQR[9 * (size_t)j + 3 * h + c] = QR[h][c]; }
         S *dinv = e->dinv + 3 * (size_t)j, *t = e->t + 3 * (size_t)j, *tri = e->tri + 6 * (size_t)j;
         const S *mq1 = o->mq1 + 3 * (size_t)j;
         dinv[0] = dinv[1] = dinv[2] = 1;
@@ -592,6 +656,11 @@ static void FN(more_trial)(int M, const int *pt_ptr, S lambda, const FN(more_t) 
  * oracle's rounding noise decides where its free run stops. */
 static int ora_wide_sums_flag = 0;
 void ora_set_wide_sums(int on) { ora_wide_sums_flag = on; }
+/* MOREQR's right block QR only (solve_more_qr) instead of the LDL^T of S = (Jc'Jc + lambda I) - sum Z Z': off by default, like the
+ * product's BA_MOREQR_QR switch (round 4: the route exists on both sides and agrees to 1e-7 / 1e-10 on the first step; the product's
+ * dense QR kernels have a sporadic accuracy defect that keeps it from being the default). */
+static int ora_more_qr_flag = 0;
+void ora_set_more_qr(int on) { ora_more_qr_flag = on; }
 #endif
 static void FN(build_reduced)(int N, int K, const int *cam_idx, const int *pt_idx, const int *pt_ptr, int M,
                               const S *Jc, const S *fvec, S lambda, const FN(elim_t) * e, S *Smat, S *rhs, S *gc)
@@ -708,14 +777,13 @@ static void FN(backsub)(int M, const int *pt_ptr, const int *cam_idx, const FN(e
  * projected rows are  P_j [A;0] with P_j = Q2^T; since only the span matters for the least-squares solve,
  * the oracle uses the equivalent (I - Q1 Q1^T)[A;0] rows (same R up to an orthogonal row transform).
  * Sized for small problems only (dense (2K+3M+D) x D). */
-static int FN(solve_reduced_qr)(int N, int M, int K, const int *cam_idx, const int *pt_ptr, const S *Jc, const S *fvec,
-                                S lambda, const S *Q1obs, const S *Q1lam, S *dxc)
+/* J2bot (m = 2K + 3M + D rows) and b2 = -qtb2 from the point blocks' thin Q: shared by QRKIT (lambda > 0) and by MOREQR's outer
+ * factorisation (lambda = 0: the camera rows are zero). */
+static void FN(build_j2bot)(int N, int M, int K, const int *cam_idx, const int *pt_ptr, const S *Jc, const S *fvec,
+                            S lambda, const S *Q1obs, const S *Q1lam, S *A2, S *b2)
 {
     const int D = 9 * N;
     const size_t m = 2 * (size_t)K + 3 * (size_t)M + D;
-    S *A2 = (S *)calloc(m * D, sizeof(S));
-    S *b2 = (S *)calloc(m, sizeof(S));
-    if (!A2 || !b2) { free(A2); free(b2); return -1; }
     for (int j = 0; j < M; j++) {
         const int i0 = pt_ptr[j], k = pt_ptr[j + 1] - i0;
         const size_t row0 = 2 * (size_t)i0 + 3 * (size_t)j;
@@ -762,10 +830,88 @@ static int FN(solve_reduced_qr)(int N, int M, int K, const int *cam_idx, const i
     for (int c = 0; c < D; c++) A2[(size_t)c * m + 2 * (size_t)K + 3 * (size_t)M + c] = sl;
     /* min || J2bot dx_c + qtb2 || */
     for (size_t r = 0; r < m; r++) b2[r] = -b2[r];
+}
+
+static int FN(solve_reduced_qr)(int N, int M, int K, const int *cam_idx, const int *pt_ptr, const S *Jc, const S *fvec,
+                                S lambda, const S *Q1obs, const S *Q1lam, S *dxc)
+{
+    const int D = 9 * N;
+    const size_t m = 2 * (size_t)K + 3 * (size_t)M + D;
+    S *A2 = (S *)calloc(m * D, sizeof(S));
+    S *b2 = (S *)calloc(m, sizeof(S));
+    if (!A2 || !b2) { free(A2); free(b2); return -1; }
+    FN(build_j2bot)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, Q1obs, Q1lam, A2, b2);
     FN(dense_qr_solve)((int)m, D, A2, b2, dxc);
     free(A2);
     free(b2);
     return 0;
+}
+
+/* MOREQR's right block, QR only (BacktrackLevMarqMore.h:288-345; round 4 -- rounds 1 - 3 formed S = (Jc'Jc + lambda I) - sum Z Z' and
+ * factored it by LDL^T: the same camera step in exact arithmetic, the conditioning of the normal equations in floating point).
+ *   outer (:288-291, m_solver.compute(J), once per outer iteration; recomputed per call here): the block-angular QR of J -- the point
+ *     blocks by more_outer (lambda = 0), then the dense QR of J2bot(lambda = 0) -> R22 (D x D), c2 = the head of Q^T (-qtb2);
+ *   inner (:297-345, m_solverInner.compute([R ; sqrt(lambda) I]) per trial): the point blocks [sqrt(lambda) I3 ; R1_j] by more_trial
+ *     (thin Q = [Ql ; QR], 6 x 3), then the dense QR of the rows left for the camera columns:
+ *       per point the complement (I - Q Q^T) [0 ; R12_j] (6 rows; rhs (I - Q Q^T) [0 ; -q1_j]) -- the rows orthogonal to the point's
+ *       thin Q up to an orthogonal row transform, like J2bot --, R22 (rhs c2) and sqrt(lambda) I_D (rhs 0);
+ *     dx_c from R y = Q^T rhs (the rhs columns carry the NEGATIVE residual parts throughout), the points by backsub.
+ * No normal equations anywhere. */
+static int FN(solve_more_qr)(int N, int M, int K, const int *cam_idx, const int *pt_ptr, const S *Jc, const S *fvec, S lambda,
+                             const FN(more_t) * o, const S *Q1obs, const S *Q1lam, const FN(elim_t) * e, const S *mQl, const S *mQR, S *dxc)
+{
+    const int D = 9 * N;
+    int rc = -1;
+    const size_t mo = 2 * (size_t)K + 3 * (size_t)M + D, mi = 6 * (size_t)M + 2 * (size_t)D;
+    S *R22 = (S *)malloc(sizeof(S) * (size_t)D * D), *c2 = (S *)malloc(sizeof(S) * (size_t)D);
+    S *A2 = (S *)calloc(mo * D, sizeof(S)), *b2 = (S *)calloc(mo, sizeof(S));
+    S *Ai = NULL, *bi = NULL, *Ri = NULL, *ci = NULL;
+    if (!R22 || !c2 || !A2 || !b2) goto done;
+    FN(build_j2bot)(N, M, K, cam_idx, pt_ptr, Jc, fvec, (S)0, Q1obs, Q1lam, A2, b2);
+    if (FN(dense_qr_factor_tsqr)(mo, D, A2, b2, R22, c2)) goto done;
+    free(A2); free(b2); A2 = b2 = NULL;
+    Ai = (S *)calloc(mi * D, sizeof(S)); bi = (S *)calloc(mi, sizeof(S));
+    Ri = (S *)malloc(sizeof(S) * (size_t)D * D); ci = (S *)malloc(sizeof(S) * (size_t)D);
+    if (!Ai || !bi || !Ri || !ci) goto done;
+    for (int j = 0; j < M; j++) {
+        const S *Ql = mQl + 9 * (size_t)j, *QR = mQR + 9 * (size_t)j;
+        const size_t row0 = 6 * (size_t)j;
+        for (int i = pt_ptr[j]; i < pt_ptr[j + 1]; i++) {
+            const S *Z0 = o->R12T + 27 * (size_t)i, *Z = e->Z + 27 * (size_t)i; /* 9 x 3: Z0[c][r] = R12_j(r, c); Z = Z0 QR */
+            const int a = cam_idx[i];
+            for (int c = 0; c < 9; c++) {
+                S *col = Ai + (size_t)(9 * a + c) * mi + row0;
+                for (int rr = 0; rr < 3; rr++) {
+                    col[rr] -= Ql[3 * rr] * Z[3 * c] + Ql[3 * rr + 1] * Z[3 * c + 1] + Ql[3 * rr + 2] * Z[3 * c + 2];
+                    col[3 + rr] += Z0[3 * c + rr] - (QR[3 * rr] * Z[3 * c] + QR[3 * rr + 1] * Z[3 * c + 1] + QR[3 * rr + 2] * Z[3 * c + 2]);
+                }
+            }
+        }
+        const S *mq1 = o->mq1 + 3 * (size_t)j, *t = e->t + 3 * (size_t)j; /* t = QR^T (-q1) */
+        for (int rr = 0; rr < 3; rr++) {
+            bi[row0 + rr] = -(Ql[3 * rr] * t[0] + Ql[3 * rr + 1] * t[1] + Ql[3 * rr + 2] * t[2]);
+            bi[row0 + 3 + rr] = mq1[rr] - (QR[3 * rr] * t[0] + QR[3 * rr + 1] * t[1] + QR[3 * rr + 2] * t[2]);
+        }
+    }
+    {
+        const S sl = SQRT(lambda);
+        const size_t rR = 6 * (size_t)M, rL = rR + (size_t)D;
+        for (int c = 0; c < D; c++) {
+            for (int i = 0; i <= c; i++) Ai[(size_t)c * mi + rR + i] = R22[(size_t)c * D + i];
+            bi[rR + c] = c2[c];
+            Ai[(size_t)c * mi + rL + c] = sl;
+        }
+    }
+    if (FN(dense_qr_factor_tsqr)(mi, D, Ai, bi, Ri, ci)) goto done;
+    for (int j = D - 1; j >= 0; j--) {
+        S a = ci[j];
+        for (int c = j + 1; c < D; c++) a -= Ri[(size_t)c * D + j] * dxc[c];
+        dxc[j] = a / Ri[(size_t)j * D + j];
+    }
+    rc = 0;
+done:
+    free(R22); free(c2); free(A2); free(b2); free(Ai); free(bi); free(Ri); free(ci);
+    return rc;
 }
 
 /* QRSPQR (kind 4): SuiteSparseQR on the WHOLE [J ; sqrt(lambda) I] (typedef SPQR<JacobianType> SchurlikeQRSolver, BAFunctor.h:113-116;
@@ -855,21 +1001,25 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     S *Smat = (S *)malloc(sizeof(S) * (size_t)D * D);
     S *rhs = (S *)malloc(sizeof(S) * (size_t)D);
     S *gc = (S *)malloc(sizeof(S) * (size_t)D);
-    S *Q1obs = NULL, *Q1lam = NULL;
+    S *Q1obs = NULL, *Q1lam = NULL, *mQl = NULL, *mQR = NULL;
+    FN(more_t) mo;
+    mo.R12T = NULL; mo.R1 = NULL; mo.mq1 = NULL; mo.perm = NULL;
     int rc = 0;
     if (kind == 2) {
         FN(elim_cholesky)(M, pt_ptr, Jc, Jp, fvec, lambda, &e);
     } else if (kind == 3) {
         /* the outer factorisation is redone per call here (the reference does it once per outer iteration,
          * BacktrackLevMarqMore.h:288; same numbers) */
-        FN(more_t) o;
-        o.R12T = (S *)malloc(sizeof(S) * 27 * (size_t)(K > 0 ? K : 1));
-        o.R1 = (S *)malloc(sizeof(S) * 6 * (size_t)(M > 0 ? M : 1));
-        o.mq1 = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
-        o.perm = e.perm; /* the outer QR's column permutation carries through the inner QR to the step */
-        FN(more_outer)(M, pt_ptr, Jc, Jp, fvec, &o);
-        FN(more_trial)(M, pt_ptr, lambda, &o, &e);
-        free(o.R12T); free(o.R1); free(o.mq1);
+        mo.R12T = (S *)malloc(sizeof(S) * 27 * (size_t)(K > 0 ? K : 1));
+        mo.R1 = (S *)malloc(sizeof(S) * 6 * (size_t)(M > 0 ? M : 1));
+        mo.mq1 = (S *)malloc(sizeof(S) * 3 * (size_t)(M > 0 ? M : 1));
+        mo.perm = e.perm; /* the outer QR's column permutation carries through the inner QR to the step */
+        Q1obs = (S *)malloc(sizeof(S) * 6 * (size_t)(K > 0 ? K : 1));
+        Q1lam = (S *)malloc(sizeof(S) * 9 * (size_t)(M > 0 ? M : 1));
+        mQl = (S *)malloc(sizeof(S) * 9 * (size_t)(M > 0 ? M : 1));
+        mQR = (S *)malloc(sizeof(S) * 9 * (size_t)(M > 0 ? M : 1));
+        FN(more_outer)(M, pt_ptr, Jc, Jp, fvec, &mo, Q1obs, Q1lam);
+        FN(more_trial)(M, pt_ptr, lambda, &mo, &e, mQl, mQR);
     } else {
         if (kind == 0) {
             Q1obs = (S *)malloc(sizeof(S) * 6 * (size_t)K);
@@ -887,6 +1037,8 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
         rc = FN(solve_whole_qr)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, lambda, dx);
     } else if (kind == 0) {
         rc = FN(solve_reduced_qr)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, Q1obs, Q1lam, dxc);
+    } else if (kind == 3 && ora_more_qr_flag) { /* QR only: the reduced system above only serves Sout / rhsout (what the default LDL^T form factors) */
+        rc = FN(solve_more_qr)(N, M, K, cam_idx, pt_ptr, Jc, fvec, lambda, &mo, Q1obs, Q1lam, &e, mQl, mQR, dxc);
     } else {
         FN(dense_ldlt)(D, Smat);
         FN(dense_ldlt_solve)(D, Smat, rhs);
@@ -894,7 +1046,8 @@ int FN(ora_step)(int kind, int N, int M, int K, const int *cam_idx, const int *p
     }
     if (!assemble_only && kind != 4) FN(backsub)(M, pt_ptr, cam_idx, &e, dx);
     if (gout || diagmax) FN(grad_diag)(N, M, K, cam_idx, pt_idx, Jc, Jp, fvec, gout, diagmax);
-    free(Q1obs); free(Q1lam);
+    free(Q1obs); free(Q1lam); free(mQl); free(mQR);
+    free(mo.R12T); free(mo.R1); free(mo.mq1);
     free(e.Z); free(e.dinv); free(e.t); free(e.tri); free(e.perm);
     free(Smat); free(rhs); free(gc); free(pt_ptr);
     return rc;

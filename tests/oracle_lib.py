@@ -47,6 +47,11 @@ def set_wide_sums(on):
     lib().ora_set_wide_sums(int(bool(on)))
 
 
+def set_more_qr(on):
+    """MOREQR's right block QR only (ba_oracle_impl.h: solve_more_qr) instead of the LDL^T of S -- the counterpart of BA_MOREQR_QR=1."""
+    lib().ora_set_more_qr(int(bool(on)))
+
+
 def set_threads(n):
     """OpenMP threads of the dense factorisation (results do not depend on it)."""
     lib().ora_set_threads(int(n))

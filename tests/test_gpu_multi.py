@@ -31,6 +31,9 @@ class DevArray:
 
 def _worker(rank, world, port, kind, out_q):
     sys.path.insert(0, ROOT)
+    if kind >= 10:  # 13: MOREQR on its QR-only route (BA_MOREQR_QR=1: the shards' R factors meet in the TSQR stack, twice per accepted step)
+        os.environ["BA_MOREQR_QR"] = "1"
+        kind -= 10
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -140,11 +143,13 @@ def test_two_ranks_natural_stop_same_number_of_collectives(ba, gpu_ok):
     assert abs(e0 - ref["energy"]) < 3e-2 * ref["energy"]
 
 
-@pytest.mark.parametrize("kind", [2, 1, 3, 0])  # (0 = QRKIT: distributed TSQR -- the shards' R factors are what is all-reduced, no normal equations)
+@pytest.mark.parametrize("kind", [2, 1, 3, 0, 13])  # (0 = QRKIT: distributed TSQR -- the shards' R factors are what is all-reduced, no normal equations; 13 = MOREQR, QR only)
 @pytest.mark.timeout(600)
-def test_two_ranks_match_one_rank(ba, gpu_ok, kind):
+def test_two_ranks_match_one_rank(ba, gpu_ok, kind, monkeypatch):
     p = ba.Problem.synthetic(24, 3000, 10500, 77)
-    s = ba.Solver(p, kind, ba.F64)
+    if kind >= 10:
+        monkeypatch.setenv("BA_MOREQR_QR", "1")
+    s = ba.Solver(p, kind % 10, ba.F64)
     e0, dmax = s.linearize()
     ref = s.minimize(max_trials=NTR)
     del s
