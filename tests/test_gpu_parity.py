@@ -594,6 +594,7 @@ def test_moreqr_qr_only_route(ba, O, gpu_ok, prob21, monkeypatch):
             s.linearize(False)
             et, _, _ = s.try_step(run["trace"][k][5])
             assert abs(et - run["trace"][k][6]) < 1e-9 * et, (k, et, run["trace"][k][6])
+        s = ba.Solver(prob21, ba.MOREQR, ba.F64)  # (from the file's start again)
         r = s.minimize(max_trials=8)  # the production loop on this route (outer QR behind the device-side step control)
         acc = r["trace"][r["trace"][:, 1] == 1]
         assert len(acc) >= 5 and np.all(np.diff(acc[:, 2]) < 0)
