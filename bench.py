@@ -367,7 +367,7 @@ def main():
             ach = flops_factor / (ph["dense_factor"] * 1e-3) / 1e12
             # traffic: HBM bytes need PMC passes of their own (rocprofv3 --pmc cannot ride on this run): scripts/evidence.sh collects
             # them with this same command; the line quotes the committed per-launch figure and names its file
-            out["roofline"] = {"bound": "mfma", "kernel": "k_ldlt_step<%s,64> (fused panel + trailing update of the dense LDL^T of the %dx%d reduced camera matrix; k_ldlt_panel for the first block column)" % ("double" if S == 8 else "float", D, D),
+            out["roofline"] = {"bound": "mfma", "kernel": "%s<%s,64> (fused panel + trailing update of the dense LDL^T of the %dx%d reduced camera matrix; k_ldlt_panel for the first block column)" % ("k_ldlt_step2" if D >= 3072 else "k_ldlt_step", "double" if S == 8 else "float", D, D),
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "launches_per_trial": nblk, "avg_launch_us": 1e3 * ph["dense_factor"] / nblk,
                                "algorithmic_flops_per_launch": flops_factor / nblk, "ms_per_trial": ph["dense_factor"],

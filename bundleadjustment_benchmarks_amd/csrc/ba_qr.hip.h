@@ -159,8 +159,12 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 // that is in profiles/EXPERIMENTS.md 6.3)
 __device__ int ba_qr_hw_sqrt_flag = 0;
 __device__ int ba_qr_dbg_flag = 0; // diagnostic bits (BA_QR_DBG): 1 = full barrier in the step loop, 2 = agent acquire before the T factor re-reads V
-__device__ __forceinline__ float ba_qr_sqrt(float x) { return ba_qr_hw_sqrt_flag ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
-__device__ __forceinline__ double ba_qr_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float ba_qr_sqrt(float x, int hw) { return hw ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ __forceinline__ double ba_qr_sqrt(double x, int) { return sqrt(x); }
+// below this alpha^2 + |x|^2 a reflector's norm is formed again from entries scaled by `up` (a power of two: exact)
+template <typename T> struct ba_qr_tiny;
+template <> struct ba_qr_tiny<float> { static constexpr float s2 = 0x1p-80f, up = 0x1p60f; };
+template <> struct ba_qr_tiny<double> { static constexpr double s2 = 0x1p-900, up = 0x1p500; };
 __device__ __forceinline__ float ba_qr_rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = blockIdx.x;
     const int nsb = min(NSB, nsb_total - g * NSB), rows = BA_QR_PB * nsb;
     if (threadIdx.x < BA_QR_PB) taus[threadIdx.x] = (T)0;
+    const int hw_sqrt = ba_qr_hw_sqrt_flag, dbg_bits = ba_qr_dbg_flag; // (read ONCE: a load of a global per reflector step sits on the panel's critical path)
 #ifdef BA_QR_STAMP
     if (nch == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_stamp[36] = (long long)t_; }
 #endif
@@ -220,16 +225,33 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
         const T alpha = ba_readlane_dyn(a[0][pos], j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
         T tj = 0, sc = 0, beta = alpha;
         if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
-            const T nb = ba_qr_sqrt(alpha * alpha + x2);
-            // nb == 0 with x2 != 0: the squared norm is a DENORMAL (config 3, fp32: a k1 column of a chunk that only holds entries of
-            // ~1e-21 -- squares of ~1e-42) and the square root flushed it.  sqrtf does not (a denormal's root is a normal number), the
-            // bare v_sqrt_f32 does: beta = 0, tau = 0 * inf = NaN, and every later column of the panel is NaN -- round 3's "no LM step
-            // accepted" with the hardware square root (profiles/EXPERIMENTS.md 6.3).  Such a column is zero to working precision:
-            // identity reflector, like x2 == 0.
+            T s2 = alpha * alpha + x2, al = alpha, up = (T)1;
+            // A column whose entries are so small that their SQUARES fall into the denormal range (fp64: entries below ~1e-150, the
+            // noise-of-noise a chunk of low row rank leaves in its later columns; fp32: real data, a k1 / k2 column with entries of
+            // ~1e-21): the sum of squares above has a few bits, beta and tau stop fitting v, and H = I - tau v v^T is not orthogonal
+            // any more (round 4's self-check: 5e-2 off in one chunk of problem-21's panel 2; profiles/r04_qr_selfcheck.txt).  LAPACK's
+            // dlarfg rescales such a column; so does this branch (rare, wave-uniform): the norm again from entries scaled by a power
+            // of two, v = (x up) / (alpha up - beta up), beta = (beta up) / up.  A column that is zero even then keeps the identity.
+            if (s2 < ba_qr_tiny<T>::s2) {
+                up = ba_qr_tiny<T>::up;
+                T ps = 0;
+#pragma unroll
+                for (int e = 0; e < RPL; e++) {
+                    const T y = a[e][pos] * up;
+                    ps += (lane + 64 * e > j) ? y * y : (T)0;
+                }
+                al = alpha * up;
+                const T x2s = ba_wave_sum_all<T>(ps);
+                s2 = x2s != (T)0 ? al * al + x2s : (T)0;
+            }
+            const T nb = s2 != (T)0 ? ba_qr_sqrt(s2, hw_sqrt) : (T)0;
+            // nb == 0 with s2 != 0: the bare v_sqrt_f32 (BA_QR_HW_SQRT=1) flushes a denormal argument -- round 3's "no LM step accepted"
+            // at config 3 with the hardware square root: beta = 0, tau = 0 * inf = NaN (profiles/EXPERIMENTS.md 6.3).  Identity reflector.
             if (nb != (T)0) {
-                beta = alpha > (T)0 ? -nb : nb;
-                tj = (beta - alpha) * ba_qr_rcp(beta);
-                sc = ba_qr_rcp(alpha - beta);
+                const T bs = al > (T)0 ? -nb : nb;
+                tj = (bs - al) * ba_qr_rcp(bs);
+                sc = up * ba_qr_rcp(al - bs);
+                beta = bs * ba_qr_rcp(up);
             }
         }
         if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             if (jw == wv) form(jq, j);     // (wave-uniform) this wave's column jq is column j
             // LDS-only barrier: the hand-over goes through LDS; __syncthreads() would also wait for the owner's global stores of the
             // retired column
-            if (ba_qr_dbg_flag & 1) __syncthreads();
+            if (dbg_bits & 1) __syncthreads();
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef BA_QR_STAMP
             long long t_exit = 0;
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #endif
     // ---- T factor.  The retired columns are in memory (written by different waves of this workgroup: visible behind the barrier).
     __syncthreads();
-    if (ba_qr_dbg_flag & 2) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
+    if (dbg_bits & 2) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
     {
         typedef typename ba_acc<T>::type acc_t;
         const int i = lane & 15, q = lane >> 4;
@@ -669,7 +691,10 @@ inline void ba_qr_factor(hipStream_t st, T *A, size_t lda, int mrows, int D, T *
         else
             hipLaunchKernelGGL((k_qr_apply<T, NSBU>), ga, dim3(64 * BA_QR_AW), 0, sa, A, lda, c0, bw, c0, level, stride, nsb, tl, col0, col1, nch, nct, sd.go);
     };
+    const char *stop_env = getenv("BA_QR_STOP_PANEL"); // diagnostic: leave the factorisation behind this panel (its T factors stay in tau_all)
+    const int stop_panel = stop_env ? atoi(stop_env) : -1;
     for (int c0 = 0; c0 < D; c0 += BA_QR_PB) {
+        if (stop_panel >= 0 && c0 / BA_QR_PB > stop_panel) break;
         const int bw = D - c0 < BA_QR_PB ? D - c0 : BA_QR_PB;
         const int col0 = c0 + bw, col1 = D + 1; // trailing columns incl. the right-hand side
         const int colm = la ? (col0 + BA_QR_PB < col1 ? col0 + BA_QR_PB : col1) : col0; // look-ahead: [col0, colm) is the next panel

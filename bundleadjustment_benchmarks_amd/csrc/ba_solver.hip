@@ -1109,6 +1109,27 @@ template <typename T> struct Solver final : SolverBase {
             for (int c = 0; c < 2 * D; c++) out[c] = (double)hh[c];
             return BA_OK;
         }
+        case 15:   // diagnostic (BA_DBG_QRCHECK): the matrix of the last dense solve as built, inner_rows() x (D + 1) column-major
+        case 16: { // diagnostic: the same matrix as the factorisation left it (R, reflectors in place, Q^T rhs in column D)
+            const size_t rows = (size_t)inner_rows();
+            const T *src = what == 15 ? d_qAcopy.p : d_qA.p;
+            if (!dense_qr() || n != rows * (D + 1) || !src) return BA_ERR_ARG;
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<T> col(rows);
+            for (int c = 0; c <= D; c++) {
+                HIPCHK(hipMemcpy(col.data(), src + (size_t)c * q_lda, sizeof(T) * rows, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < rows; i++) out[(size_t)c * rows + i] = (double)col[i];
+            }
+            return BA_OK;
+        }
+        case 17: { // diagnostic: the T factors of the LAST panel factored (BA_QR_TAU_LEVELS level slots of q_tau_stride scalars)
+            if (!dense_qr() || n != (size_t)BA_QR_TAU_LEVELS * q_tau_stride || !d_qtau.p) return BA_ERR_ARG;
+            std::vector<T> hh;
+            int rcg;
+            if ((rcg = dl(d_qtau.p, n, hh))) return rcg;
+            for (size_t c = 0; c < n; c++) out[c] = (double)hh[c];
+            return BA_OK;
+        }
         case 13: { // diagnostic (BA_DBG_ATB): A^T b of MOREQR's inner matrix as built
             if (!more_qr() || n != (size_t)D) return BA_ERR_ARG;
             std::vector<T> hh;

@@ -38,6 +38,6 @@ if has control; then
   echo control done
 fi
 if has configs; then
-  python3 $R/scripts/run_configs.py cfg2 cfg3 cfg1 cfg4 > $O/configs_to_termination.jsonl 2> $O/configs.err
+  python3 $R/scripts/run_configs.py ${CFGS:-cfg2 cfg3 cfg1 cfg4} > $O/configs_to_termination.jsonl 2> $O/configs.err
   echo configs done
 fi
