@@ -859,12 +859,21 @@ __global__ __launch_bounds__(256) void k_more_build(int K, int Ml, int D, const 
 {
     const int ia = blockIdx.x * 256 + threadIdx.x;
     if (ia >= K) return;
-    const int j = obs_pt[ia], a = obs_cam[ia];
+    const int j = obs_pt[ia], a = obs_cam[ia], b = pt_ptr[j], e = pt_ptr[j + 1];
+    for (int i2 = b; i2 < ia; i2++) // (several observations of one camera by one point: the first writes the sum of their blocks -- k_qrkit_build)
+        if (obs_cam[i2] == a) return;
     const size_t r0 = 6 * (size_t)j;
     T Ql[9], QR[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) { Ql[q] = mQl[9 * (size_t)j + q]; QR[q] = mQR[9 * (size_t)j + q]; }
-    const T *z0 = rec0 + (size_t)ia * BA_REC, *z = rec + (size_t)ia * BA_REC;
+    T z0[27], z[27];
+#pragma unroll
+    for (int q = 0; q < 27; q++) { z0[q] = rec0[(size_t)ia * BA_REC + q]; z[q] = rec[(size_t)ia * BA_REC + q]; }
+    for (int i2 = ia + 1; i2 < e; i2++)
+        if (obs_cam[i2] == a) {
+#pragma unroll
+            for (int q = 0; q < 27; q++) { z0[q] += rec0[(size_t)i2 * BA_REC + q]; z[q] += rec[(size_t)i2 * BA_REC + q]; }
+        }
     T *colbase = A + (size_t)(9 * a) * lda + r0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {

@@ -63,10 +63,20 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
     if (cam_rows && ia < D) A[(size_t)ia * lda + 2 * (size_t)K + 3 * (size_t)Ml + ia] = sqrt(*lam); // camera rows: sqrt(lambda) I_D, zero rhs
     if (ia >= K) return;
     const int j = obs_pt[ia], a = obs_cam[ia], b = pt_ptr[j], e = pt_ptr[j + 1];
+    // A camera may see a point more than once (legal input: the reference's sparse J just has more rows): the blocks of those
+    // observations ADD UP in the 9 columns of the camera.  The first of them writes the sum (Z summed in observation order), the
+    // others write nothing -- no atomics, and the same bits as before where every (point, camera) pair occurs once.
+    for (int i2 = b; i2 < ia; i2++)
+        if (obs_cam[i2] == a) return;
     const size_t r0 = 2 * (size_t)b + 3 * (size_t)j;
     T Z[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) Z[q] = rec[(size_t)ia * BA_REC + q];
+    for (int i2 = ia + 1; i2 < e; i2++)
+        if (obs_cam[i2] == a) {
+#pragma unroll
+            for (int q = 0; q < 27; q++) Z[q] += rec[(size_t)i2 * BA_REC + q];
+        }
     T *colbase = A + (size_t)(9 * a) * lda;
     for (int ib = b; ib < e; ib++) {
         const T *Q = q1obs + 6 * (size_t)ib; // 2 x 3 row-major
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
         for (int c = 0; c < 9; c++)
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
-                T v = (ib == ia) ? Jc[(size_t)(9 * rr + c) * K + ia] : (T)0;
+                T v = (obs_cam[ib] == a) ? Jc[(size_t)(9 * rr + c) * K + ib] : (T)0;
                 v -= q[3 * rr] * Z[3 * c] + q[3 * rr + 1] * Z[3 * c + 1] + q[3 * rr + 2] * Z[3 * c + 2];
                 colbase[(size_t)c * lda + r0 + 2 * (size_t)(ib - b) + rr] = v;
             }
@@ -192,7 +202,13 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #ifdef BA_QR_STAMP
     if (nch == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ba_qr_stamp[36] = (long long)t_; }
 #endif
-    T a[RPL][CW];
+    // The chunk's columns live in PAIRS of rows per register pair (rows lane + 64 e, e = 2 k and 2 k + 1): the dot products and the
+    // rank-1 updates of the step loop are v_pk_fma_f32 in fp32 -- two rows per instruction, the packed rate is the fp32 vector peak --
+    // (fp64: two v_fma_f64 per pair, nothing lost).  The step loop is bound by the issue rate of the vector unit (two waves per SIMD).
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    static_assert(RPL % 2 == 0, "rows per lane come in pairs");
+    constexpr int RP2 = RPL / 2;
+    T2 a[RP2][CW];
     size_t grow[RPL];
 #pragma unroll
     for (int e = 0; e < RPL; e++) {
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #pragma unroll
         for (int q = 0; q < CW; q++) {
             const int c = NW * q + wv;
-            a[e][q] = A[(size_t)(c0 + (c < bw ? c : 0)) * lda + grow[e]]; // (unconditional; masked below, behind ALL the loads)
+            a[e >> 1][q][e & 1] = A[(size_t)(c0 + (c < bw ? c : 0)) * lda + grow[e]]; // (unconditional; masked below, behind ALL the loads)
         }
     }
 #pragma unroll
@@ -210,19 +226,20 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
 #pragma unroll
         for (int q = 0; q < CW; q++) {
             const int c = NW * q + wv;
-            T x = a[e][q];
+            T x = a[e >> 1][q][e & 1];
             asm volatile("" : "+v"(x));
-            a[e][q] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? x : (T)0;
+            a[e >> 1][q][e & 1] = (c < bw && l < rows && (level == 1 || (l & 31) <= c)) ? x : (T)0;
         }
     }
     // reflector of column j from this wave's register column `pos` (a compile-time position after unrolling): into the LDS buffer
-    // j & 1, the column retired to memory
+    // j & 1, the column retired to memory.  (Rows l = lane + 64 e with e >= 1 lie below every pivot: j < 32.)
     auto form = [&](int pos, int j) {
-        T part = 0;
+        const T a0 = a[0][pos][0]; // row `lane`: the only one that can be the pivot row or lie above it
+        T2 p2 = {lane > j ? a0 * a0 : (T)0, a[0][pos][1] * a[0][pos][1]};
 #pragma unroll
-        for (int e = 0; e < RPL; e++) part += (lane + 64 * e > j) ? a[e][pos] * a[e][pos] : (T)0;
-        const T x2 = ba_wave_sum_all<T>(part);
-        const T alpha = ba_readlane_dyn(a[0][pos], j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
+        for (int k = 1; k < RP2; k++) p2 = __builtin_elementwise_fma(a[k][pos], a[k][pos], p2);
+        const T x2 = ba_wave_sum_all<T>(p2[0] + p2[1]);
+        const T alpha = ba_readlane_dyn(a0, j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
         T tj = 0, sc = 0, beta = alpha;
         if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
             T s2 = alpha * alpha + x2, al = alpha, up = (T)1;
@@ -234,11 +251,12 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             // of two, v = (x up) / (alpha up - beta up), beta = (beta up) / up.  A column that is zero even then keeps the identity.
             if (s2 < ba_qr_tiny<T>::s2) {
                 up = ba_qr_tiny<T>::up;
-                T ps = 0;
+                const T y0 = a0 * up, y1 = a[0][pos][1] * up;
+                T ps = (lane > j ? y0 * y0 : (T)0) + y1 * y1;
 #pragma unroll
-                for (int e = 0; e < RPL; e++) {
-                    const T y = a[e][pos] * up;
-                    ps += (lane + 64 * e > j) ? y * y : (T)0;
+                for (int k = 1; k < RP2; k++) {
+                    const T2 y = a[k][pos] * up;
+                    ps += y[0] * y[0] + y[1] * y[1];
                 }
                 al = alpha * up;
                 const T x2s = ba_wave_sum_all<T>(ps);
@@ -258,12 +276,16 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
         // the hand-over first (the others wait for it), then the column's way to memory: a masked-out element goes to a scratch word
         // (this chunk's T block, which the tail overwrites behind a full barrier) -- a select on the address instead of a branch per element
         T keep[RPL];
+        {
+            const T ve = lane > j ? a0 * sc : (lane == j ? (T)1 : (T)0);
+            vs[j & 1][lane] = ve;
+            keep[0] = lane > j ? ve : (lane == j ? beta : a0);
+        }
 #pragma unroll
-        for (int e = 0; e < RPL; e++) {
-            const int l = lane + 64 * e;
-            const T ve = l > j ? a[e][pos] * sc : (l == j ? (T)1 : (T)0);
-            vs[j & 1][l] = ve;
-            keep[e] = l > j ? ve : (l == j ? beta : a[e][pos]);
+        for (int e = 1; e < RPL; e++) {
+            const T ve = a[e >> 1][pos][e & 1] * sc;
+            vs[j & 1][lane + 64 * e] = ve;
+            keep[e] = ve;
         }
         T *const junk = Tout + (size_t)g * (BA_QR_PB * BA_QR_PB) + lane;
 #pragma unroll
@@ -275,20 +297,23 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
     };
     // w_c = tau (v . a_c), a_c -= v w_c for the register columns q0 .. CW - 1 (v is 1 on its pivot row, zero above): all dot products
     // first, then all wave reductions, then the updates -- the DPP chains of the columns interleave
-    auto update_from = [&](int q0, const T (&v)[RPL], T tj) {
+    auto update_from = [&](int q0, const T2 (&v)[RP2], T tj) {
         T pd[CW];
 #pragma unroll
         for (int q = q0; q < CW; q++) {
-            pd[q] = 0;
+            T2 d2 = v[0] * a[0][q];
 #pragma unroll
-            for (int e = 0; e < RPL; e++) pd[q] += v[e] * a[e][q];
+            for (int k = 1; k < RP2; k++) d2 = __builtin_elementwise_fma(v[k], a[k][q], d2);
+            pd[q] = d2[0] + d2[1];
         }
 #pragma unroll
         for (int q = q0; q < CW; q++) pd[q] = tj * ba_wave_sum_all<T>(pd[q]);
 #pragma unroll
-        for (int q = q0; q < CW; q++)
+        for (int q = q0; q < CW; q++) {
+            const T2 npd = {-pd[q], -pd[q]};
 #pragma unroll
-            for (int e = 0; e < RPL; e++) a[e][q] -= v[e] * pd[q];
+            for (int k = 0; k < RP2; k++) a[k][q] = __builtin_elementwise_fma(v[k], npd, a[k][q]);
+        }
     };
     // In-kernel stamps (scripts/bench_qr.hip -DBA_QR_STAMP, one-workgroup launch): 1.5 - 2.0 k cycles per step at 512 rows, of which a
     // wave's update of its 3 - 4 live columns is 900 - 1400 (two waves share a SIMD's vector unit; 27 dependent-ish instructions per
@@ -312,9 +337,9 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             if (nch == 1) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); t_exit = (long long)t_; if (threadIdx.x == 0) ba_qr_stamp[j] = t_exit; }
 #endif
             const T tj = tj_s[j & 1];
-            T v[RPL];
+            T2 v[RP2];
 #pragma unroll
-            for (int e = 0; e < RPL; e++) v[e] = vs[j & 1][lane + 64 * e];
+            for (int k = 0; k < RP2; k++) { v[k][0] = vs[j & 1][lane + 128 * k]; v[k][1] = vs[j & 1][lane + 128 * k + 64]; }
             if (wv > jw) update_from(jq, v, tj);              // column NW jq + wv > j: register columns jq .. CW - 1 are live
             else if (jq + 1 < CW) update_from(jq + 1, v, tj); // column jq of this wave is retired (or being retired)
 #ifdef BA_QR_STAMP

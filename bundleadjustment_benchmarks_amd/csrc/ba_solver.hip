@@ -151,13 +151,11 @@ template <typename T> struct Solver final : SolverBase {
     int q_rows = 0;
     // QRKIT / QRSPQR always run the dense QR of J2bot -- sharded too (distributed TSQR: launch_qr_stack), never QRCHOL's normal
     // equations under another name
-    // (round 4) ... and so can MOREQR (BA_MOREQR_QR=1, read at solver creation): its right block as the dense QR of [rows left by the
-    // per-point QRs ; R22 ; sqrt(lambda) I] (BacktrackLevMarqMore.h:297-345), R22 from one dense QR of J2bot(lambda = 0) per outer
-    // iteration (:288) -- no S, no LDL^T, sharded through the same TSQR stack.  NOT the default yet: round 4's self-check of the dense QR
-    // kernels (BA_DBG_QRCHECK, scripts/diag_qrcheck.py) found that ~8 % of their solves lose accuracy (normal-equation residual 1e-9 ... 4e-5
-    // instead of 1e-13; QRKIT's too), which MOREQR's per-trial bounds against the quad referee do not forgive; the default keeps forming
-    // S = (Jc'Jc + lambda I) - sum Z Z' and factoring it by LDL^T.
-    bool more_qr_on = false;
+    // (round 4) ... and so does MOREQR: its right block is the dense QR of [rows left by the per-point QRs ; R22 ; sqrt(lambda) I]
+    // (BacktrackLevMarqMore.h:297-345), R22 from one dense QR of J2bot(lambda = 0) per outer iteration (:288) -- no S, no LDL^T, sharded
+    // through the same TSQR stack.  BA_MOREQR_QR=0 (read at solver creation) selects rounds 1 - 3's variant instead, which eliminates the
+    // points by QR and then factors S = (Jc'Jc + lambda I) - sum Z Z' by LDL^T: 20x faster, but normal equations.
+    bool more_qr_on = true;
     bool dense_qr() const { return kind == BA_QRKIT || kind == BA_QRSPQR || more_qr(); }
     bool more_qr() const { return kind == BA_MOREQR && more_qr_on; }
     DevBuf<T> d_dbg; // diagnostic buffer (BA_DBG_ATB)
@@ -219,7 +217,7 @@ template <typename T> struct Solver final : SolverBase {
     int init(const ba_problem *p, ba_solver_kind k, int rk, int wd) override
     {
         kind = k; rank = rk; world = wd;
-        more_qr_on = getenv("BA_MOREQR_QR") != nullptr && atoi(getenv("BA_MOREQR_QR")) != 0;
+        more_qr_on = !(getenv("BA_MOREQR_QR") != nullptr && atoi(getenv("BA_MOREQR_QR")) == 0);
         int rc = ba_build_structure(p, rk, wd, BA_CHUNK, 32 /* lanes of a k_cam_gram group */, &sx);
         if (rc) return rc;
         N = p->N; D = 9 * N; Ml = sx.Ml; Kl = sx.Kl;
@@ -400,10 +398,7 @@ template <typename T> struct Solver final : SolverBase {
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_hw_sqrt_flag), &on, sizeof(int)));
             }
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)
-            for (int j = 0; j < Ml; j++) // k_qrkit_build writes one (point, camera) block per observation: a camera may see a point once
-                for (int i = sx.pt_ptr[j] + 1; i < sx.pt_ptr[j + 1]; i++)
-                    for (int i2 = sx.pt_ptr[j]; i2 < i; i2++)
-                        if (sx.obs_cam[i] == sx.obs_cam[i2]) return BA_ERR_ARG;
+            // (a camera may see a point more than once: k_qrkit_build / k_more_build add such observations' blocks up -- rounds 2 - 3 refused them)
             q_rows = std::max(outer_rows(), inner_rows());
             if (more_qr()) { AL(d_mQl, 9 * M1); AL(d_mQR, 9 * M1); AL(d_R22, (size_t)D * (D + 1)); AL(d_dbg, (size_t)D); }
             if (!getenv("BA_QR_ONE_STREAM")) {

@@ -659,7 +659,7 @@ void ora_set_wide_sums(int on) { ora_wide_sums_flag = on; }
 /* MOREQR's right block QR only (solve_more_qr) instead of the LDL^T of S = (Jc'Jc + lambda I) - sum Z Z': off by default, like the
  * product's BA_MOREQR_QR switch (round 4: the route exists on both sides and agrees to 1e-7 / 1e-10 on the first step; the product's
  * dense QR kernels have a sporadic accuracy defect that keeps it from being the default). */
-static int ora_more_qr_flag = 0;
+static int ora_more_qr_flag = 1; /* MOREQR: QR-only right block (the reference's route); 0 = LDL^T of the same reduced system */
 void ora_set_more_qr(int on) { ora_more_qr_flag = on; }
 #endif
 static void FN(build_reduced)(int N, int K, const int *cam_idx, const int *pt_idx, const int *pt_ptr, int M,

@@ -15,6 +15,24 @@ from conftest import to_oracle
 pytestmark = pytest.mark.gpu
 
 
+def moreqr_route(kind, monkeypatch, O):
+    """Test parameter 13 = MOREQR's normal-equations variant (BA_MOREQR_QR=0 / set_more_qr(False): per-point QR, then S and its LDL^T --
+    the route that exercises k_more_trial -> k_schur_pairs); 3 = the QR-only default, which has no S.  -> (solver kind, has S)"""
+    if kind == 13:
+        monkeypatch.setenv("BA_MOREQR_QR", "0")
+        O.set_more_qr(False)
+        return 3, True
+    monkeypatch.delenv("BA_MOREQR_QR", raising=False)
+    O.set_more_qr(True)
+    return kind, kind in (1, 2)
+
+
+@pytest.fixture(autouse=True)
+def _moreqr_default_route(O):
+    yield
+    O.set_more_qr(True)
+
+
 def relmax(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
 
@@ -73,11 +91,13 @@ def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     lam = 1e-6 * np.sqrt(dmax) if kind == ba.MOREQR else 1e-12 * dmax  # the symbols' own lambda0
     st = O.step(kind, po, Jc, Jp, f, lam)
     et, rho_scale, dxn = s.try_step(lam)
-    S = s.get(ba.GET_S)
-    assert relmax(S, st["S"]) < 1e-11
-    assert relmax(s.get(ba.GET_RHS), st["rhs"]) < 1e-10
+    qr_only = kind == ba.MOREQR  # (no S on this route; the QR symbols' bounds: VERDICT r3 item 7)
+    if not qr_only:
+        S = s.get(ba.GET_S)
+        assert relmax(S, st["S"]) < 1e-11
+        assert relmax(s.get(ba.GET_RHS), st["rhs"]) < 1e-10
     dx = s.get(ba.GET_DX)
-    assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
+    assert np.linalg.norm(dx - st["dx"]) < (1e-7 if qr_only else 1e-6) * np.linalg.norm(st["dx"])
     # backward error of the GPU step in the normal equations (J'J + lam I) dx = -J'r, evaluated with the oracle's J
     M, N = po.M, po.N
     Jdx = np.einsum("krc,kc->kr", Jc, dx[3 * M:].reshape(N, 9)[po.cam_idx]) + \
@@ -86,7 +106,7 @@ def test_step_matches_oracle_f64(ba, O, gpu_ok, prob21, kind):
     np.add.at(JtJdx[3 * M:].reshape(N, 9), po.cam_idx, np.einsum("krc,kr->kc", Jc, Jdx))
     np.add.at(JtJdx[:3 * M].reshape(M, 3), po.pt_idx, np.einsum("krc,kr->kc", Jp, Jdx))
     res = JtJdx + lam * dx - st["g"]
-    assert np.linalg.norm(res) < 1e-9 * np.linalg.norm(st["g"])
+    assert np.linalg.norm(res) < (1e-10 if qr_only else 1e-9) * np.linalg.norm(st["g"])
     # test energy and rho denominator
     co, pt = O.retract(po, cam, po.pts, st["dx"])
     _, e_or = O.residuals(po, co, pt)
@@ -175,8 +195,9 @@ def test_stats_match_oracle(ba, O, gpu_ok, prob21):
         assert abs(sg[k] - st[k]) < 1e-12 * abs(st[k])
 
 
-@pytest.mark.parametrize("kind", [2, 1, 3])
-def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
+@pytest.mark.parametrize("kind", [2, 1, 3, 13])
+def test_small_synthetic_step(ba, O, gpu_ok, small, kind, monkeypatch):
+    kind, has_S = moreqr_route(kind, monkeypatch, O)
     po = to_oracle(small)
     cam = O.init_cams(po)
     f, e = O.residuals(po, cam, po.pts)
@@ -188,17 +209,19 @@ def test_small_synthetic_step(ba, O, gpu_ok, small, kind):
     for lam in (1e-12 * dmax, 1e-3, 10.0):
         st = O.step(kind, po, Jc, Jp, f, lam)
         s.try_step(lam)
-        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
+        if has_S:
+            assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
 
 
-@pytest.mark.parametrize("kind", [2, 1, 0, 3])
-def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
+@pytest.mark.parametrize("kind", [2, 1, 0, 3, 13])
+def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind, monkeypatch):
     """Scalar = float (src/BATypeUtils.h:6-7): one trial against the float oracle of the same symbol.
     fp32 leaves ~1e-3 on S (entries up to 1e9 accumulated from ~1e3 terms) and, through cond(S), a few percent on dx;
     the energy of the trial point must agree to 1e-3.  QRKIT (kind 0) never forms S: its right block is the dense Householder QR
-    of J2bot on both sides (ba_qr.hip.h / oracle solve_reduced_qr)."""
+    of J2bot on both sides (ba_qr.hip.h / oracle solve_reduced_qr); so does MOREQR (kind 3; 13 = its normal-equations variant)."""
+    kind, has_S = moreqr_route(kind, monkeypatch, O)
     po = to_oracle(small)
     cam = O.init_cams(po, np.float32)
     pts = po.pts.astype(np.float32)
@@ -211,7 +234,7 @@ def test_step_matches_oracle_f32(ba, O, gpu_ok, small, kind):
     for lam in (1.0, 100.0):
         st = O.step(kind, po, Jc, Jp, f, lam)
         et, rs, dn = s.try_step(lam)
-        if kind != 0:
+        if has_S:
             assert relmax(s.get(ba.GET_S), st["S"]) < 5e-3
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 5e-2 * np.linalg.norm(st["dx"])
@@ -328,8 +351,9 @@ def _ragged_problem(ba):
     return ba.Problem.from_arrays(p.N, p.M, int(keep.sum()), cam_idx, pt_idx, meas, a["cams9"], a["pts"])
 
 
-@pytest.mark.parametrize("kind", [2, 1, 3])
-def test_ragged_and_unsorted_input(ba, O, gpu_ok, kind):
+@pytest.mark.parametrize("kind", [2, 1, 3, 13])
+def test_ragged_and_unsorted_input(ba, O, gpu_ok, kind, monkeypatch):
+    kind, has_S = moreqr_route(kind, monkeypatch, O)
     p = _ragged_problem(ba)
     a = p.arrays()
     order = np.argsort(a["pt_idx"], kind="stable")  # the library sorts stably by point; the oracle needs sorted input
@@ -345,12 +369,18 @@ def test_ragged_and_unsorted_input(ba, O, gpu_ok, kind):
     for lam in (1e-3, 5.0):
         st = O.step(kind, po, Jc, Jp, f, lam)
         et, rs, dn = s.try_step(lam)
-        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
+        if has_S:
+            assert relmax(s.get(ba.GET_S), st["S"]) < 1e-11
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-7 * np.linalg.norm(st["dx"])
         assert np.all(dx[3 * 77: 3 * 77 + 3] == 0)          # the unobserved point does not move
-        blk = s.get(ba.GET_S)[45:54, 45:54]
-        assert np.allclose(blk, lam * np.eye(9), rtol=0, atol=1e-300)  # the blind camera's block is lambda I
+        if has_S:
+            blk = s.get(ba.GET_S)[45:54, 45:54]
+            assert np.allclose(blk, lam * np.eye(9), rtol=0, atol=1e-300)  # the blind camera's block is lambda I
+        else:
+            # the blind camera does not move: its columns hold nothing but sqrt(lambda) and its gradient is zero (the TSQR's chunk of the
+            # sqrt(lambda) rows mixes that row with others: zero up to rounding, not bit-zero)
+            assert np.abs(dx[3 * p.M + 45: 3 * p.M + 54]).max() < 1e-13 * np.abs(dx).max()
     r = s.minimize(max_trials=10)
     acc = r["trace"][r["trace"][:, 1] == 1]
     assert len(acc) >= 3 and np.all(np.diff(acc[:, 2]) < 0)
@@ -417,11 +447,13 @@ def test_schur_assembly_does_not_depend_on_the_dealing(ba, gpu_ok, prob21, monke
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2], (wgs, bands, window)
 
 
-@pytest.mark.parametrize("kind", [1, 3])
-def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
+@pytest.mark.parametrize("kind", [1, 3, 13, 0])
+def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind, monkeypatch):
     """Per-point QR with tracks of 40 / 100 / 200 / 300 / 700 observations (one bucket of lanes-per-point each, the last
     one with 16 observations per lane) next to ordinary short tracks; repeated observations of a camera by one point are
-    legal input."""
+    legal input -- also for the symbols that write J2bot densely (QRKIT, MOREQR: the blocks of such observations add up in the
+    camera's columns; rounds 2 - 3 refused them with BA_ERR_ARG)."""
+    kind, has_S = moreqr_route(kind, monkeypatch, O)
     p = ba.Problem.synthetic(12, 200, 800, 77)
     a = p.arrays()
     rng = np.random.default_rng(5)
@@ -449,7 +481,8 @@ def test_long_tracks_qr_buckets(ba, O, gpu_ok, kind):
     for lam in (1e-3, 2.0):
         st = O.step(kind, po, Jc, Jp, f, lam)
         s.try_step(lam)
-        assert relmax(s.get(ba.GET_S), st["S"]) < 1e-10
+        if has_S:
+            assert relmax(s.get(ba.GET_S), st["S"]) < 1e-10
         dx = s.get(ba.GET_DX)
         assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
 
@@ -553,23 +586,22 @@ def test_fused_linearisation_handles_ragged_input_and_long_tracks(ba, gpu_ok, mo
         assert len(acc) >= 3 and np.all(np.diff(acc[:, 2]) < 0)
 
 
-# ---- round 4: MOREQR with a QR-only right block (BA_MOREQR_QR=1) -------------------------------------------------------------------
+# ---- round 4: MOREQR with a QR-only right block -----------------------------------------------------------------------------------------
 def test_moreqr_qr_only_route(ba, O, gpu_ok, prob21, monkeypatch):
     """the reference's MOREQR never forms normal equations (BacktrackLevMarqMore.h:288-345) -- the block-angular QR of J
-    once per outer iteration, then of [R ; sqrt(lambda) I] per trial.  The product's default still eliminates the points by QR and then
-    factors S = (Jc'Jc + lambda I) - sum Z Z' by LDL^T; round 4 built the QR-only route on both sides -- product: BA_MOREQR_QR=1 (the dense
+    once per outer iteration, then of [R ; sqrt(lambda) I] per trial.  Since round 4 that is the route of both sides -- product: the dense
     QR of J2bot(lambda = 0) per linearisation for R22, then per trial the dense QR of [complement rows of the per-point 6 x 3 QRs ; R22 ;
-    sqrt(lambda) I] on ba_qr.hip.h's kernels; sharded through the TSQR stack); oracle: set_more_qr (solve_more_qr) -- and this test holds
-    them against each other where the route is sound: the symbol's own first step to 1e-7 with a backward error of 1e-10 (the QR symbols'
-    bounds, not the LDL^T ones), the states of the first six rows of the oracle's free run injected one by one to 1e-9 in the trial energy.
-    It is NOT the default because the dense QR kernels lose accuracy in ~8 % of their solves (profiles/r04_qr_selfcheck.txt: found with
-    this route, present in QRKIT's solves too, cause open), which this symbol's per-trial bounds against the quad referee do not forgive
-    (trial 6 of this very trajectory: 1e-4 in the camera step along the gauge directions)."""
+    sqrt(lambda) I] on ba_qr.hip.h's kernels (sharded through the TSQR stack); oracle: solve_more_qr.  Asserted with the QR symbols'
+    bounds, not the LDL^T ones: the symbol's own first step to 1e-7 with a backward error of 1e-10, the states of the first six rows of
+    the oracle's free run injected one by one to 1e-9 in the trial energy, the production loop's first rows.  Then rounds 1 - 3's variant
+    (BA_MOREQR_QR=0 / set_more_qr(False): per-point QR, then the LDL^T of S) against ITS oracle with the LDL^T bounds.
+    (The route became the default once the dense QR kernels' handling of reflectors with a denormal squared norm was repaired: before
+    that, trial 6 of this very trajectory was off by 1e-4 in the camera step along the gauge directions.)"""
     po = to_oracle(prob21)
     cam = O.init_cams(po)
     f, e = O.residuals(po, cam, po.pts)
     Jc, Jp = O.jacobian(po, cam, po.pts)
-    monkeypatch.setenv("BA_MOREQR_QR", "1")
+    monkeypatch.delenv("BA_MOREQR_QR", raising=False)
     O.set_more_qr(True)
     try:
         s = ba.Solver(prob21, ba.MOREQR, ba.F64)
@@ -599,5 +631,17 @@ def test_moreqr_qr_only_route(ba, O, gpu_ok, prob21, monkeypatch):
         acc = r["trace"][r["trace"][:, 1] == 1]
         assert len(acc) >= 5 and np.all(np.diff(acc[:, 2]) < 0)
         assert np.allclose(r["trace"][:4, 2], run["trace"][:4, 2], rtol=1e-7)
-    finally:
+        # the normal-equations variant, against the oracle's
+        monkeypatch.setenv("BA_MOREQR_QR", "0")
         O.set_more_qr(False)
+        s = ba.Solver(prob21, ba.MOREQR, ba.F64)
+        s.keep_intermediates(True)
+        eg, dmax = s.linearize()
+        st = O.step(O.MOREQR, po, Jc, Jp, f, lam)
+        s.try_step(lam)
+        S = s.get(ba.GET_S)  # (this variant has one)
+        assert np.abs(S - st["S"]).max() < 1e-11 * np.abs(st["S"]).max()
+        dx = s.get(ba.GET_DX)
+        assert np.linalg.norm(dx - st["dx"]) < 1e-6 * np.linalg.norm(st["dx"])
+    finally:
+        O.set_more_qr(True)
