@@ -669,6 +669,9 @@ __device__ __forceinline__ void ba_step_body(int nrows, int ncols, int ld, int p
     if (MACRO && u >= n64) {
         u -= n64;
         if (u >= mj.count) return;
+        // (tile rows in order, a row's tiles next to each other: consecutive workgroups = the eight XCDs share a row's Y operand.  Round 4
+        // tried one XCD per tile row -- a short row paired with a long one per XCD, operands served by that XCD's L2 alone: 8.19 against
+        // 7.78 ms at D = 9216, profiles/EXPERIMENTS.md 2)
         const int base = mj.base, nmc = ((ncols - base + 63) / 64 + 1) / 2;
         int mi = 0;
         for (;; mi++) {
@@ -822,8 +825,12 @@ __device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, in
         const T *const Yp = (panel ? W2 : W1) + (size_t)(k0 + kq) * ld + ib;
 #pragma unroll
         for (int it = 0; it < 4; it++) {
+#ifdef BA_KO_MACRO_STAGE /* knock-out experiment (scripts/bench_dense.hip): no operand loads */
+            ga[it] = v2{(T)st, (T)it}; gb[it] = v2{(T)it, (T)st}; (void)Lp; (void)Yp;
+#else
             ga[it] = *(const v2 *)(Lp + (size_t)(4 * it) * ld);
             gb[it] = *(const v2 *)(Yp + (size_t)(4 * it) * ld);
+#endif
         }
     };
     auto park = [&](int buf) {
@@ -844,7 +851,11 @@ __device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, in
             for (int u = 0; u < 4; u++)
 #pragma unroll
                 for (int v = 0; v < 4; v++)
+#ifdef BA_KO_MACRO_C /* knock-out experiment: the C tile is neither read nor written */
+                    acc[t][u][v] = (T)(t + u + v);
+#else
                     acc[t][u][v] = S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * u + li];
+#endif
     }
     park(0);
     __syncthreads();
@@ -863,12 +874,28 @@ __device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, in
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
+#ifdef BA_KO_MACRO_MFMA /* knock-out experiment: no matrix instructions */
+                    for (int u = 0; u < 4; u++) acc[t][u][(t + u) & 3] += a[t] * b[u];
+#else
                     for (int u = 0; u < 4; u++) acc[t][u] = ba_mfma(-a[t], b[u], acc[t][u]);
+#endif
             }
         }
         if (st + 1 < NST) park((st + 1) & 1);
         __syncthreads();
     }
+#ifdef BA_KO_MACRO_C
+    if (live) {
+        T sum = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) sum += acc[t][u][v];
+        if (sum == (T)123.456) S[0] = sum; // (keeps the accumulators alive)
+    }
+#else
     if (live) {
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -879,6 +906,7 @@ __device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, in
                     __hip_atomic_store(&S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * u + li], acc[t][u][v],
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#endif
 }
 
 // Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
