@@ -36,7 +36,11 @@ enum {
 
 /* Solver symbols of the reference build (src/CMakeLists.txt:95-178; src/Optimization/BAFunctor.h:98-117).
  * BA_MOREQR (src/Eigen_ext/BacktrackLevMarqMore.h): two QR factorisations per step -- J once per outer iteration,
- * [R ; sqrt(lambda) I] per trial -- and lambda0 = 1e-6 * max column norm of J. */
+ * [R ; sqrt(lambda) I] per trial -- and lambda0 = 1e-6 * max column norm of J.  Both are QR all the way (:288-345): per-point
+ * Householder QRs for the point columns, dense Householder QRs for the camera columns (J2bot(lambda = 0) per outer iteration,
+ * [rows left by the per-point 6 x 3 QRs ; R22 ; sqrt(lambda) I] per trial) -- no normal equations; needs (6 M + 2 D)(D + 1) scalars
+ * of device memory (BA_ERR_NOMEM beyond).  Environment BA_MOREQR_QR=0 at solver creation: the right block by LDL^T of the reduced
+ * camera system instead (rounds 1 - 3's variant). */
 /* BA_QRSPQR (SuiteSparseQR on the whole [J ; sqrt(lambda) I], BAFunctor.h:113-116, bundle_adjustment_large.cpp:151-157, README.md:17;
  * the library itself is absent): a sparse QR of this matrix under a fill-reducing column ordering eliminates the 3-column point
  * blocks first and is left with one dense front, J2bot -- which is the factorisation the QRKIT path performs, so the symbol runs

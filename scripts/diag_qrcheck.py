@@ -13,7 +13,7 @@ def check(s):
     r = np.empty(2 * D); ba._chk(ba.lib().ba_solver_get(s._h, 14, r.ctypes.data_as(C.c_void_p), 2 * D), "get 14")
     return np.linalg.norm(r[:D]) / np.linalg.norm(r[D:])
 rng = np.random.default_rng(0)
-for kind in [getattr(ba, k) for k in os.environ.get('KINDS', 'QRKIT').split()]: # (MOREQR: with BA_MOREQR_QR=1)
+for kind in [getattr(ba, k) for k in os.environ.get('KINDS', 'QRKIT').split()]: # (KINDS='QRKIT MOREQR')
     s = ba.Solver(p, kind, ba.F64)
     vals = []
     for k in (0, 4, 8, 12, 16, 20, 24, 28):

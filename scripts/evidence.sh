@@ -20,16 +20,18 @@ if has prof; then
   for c in cfg4 cfg5 cfg2 cfg3; do
     rocprofv3 --kernel-trace --stats -d $O/prof_$c -o $c --output-format csv -- python3 $R/bench.py --workload $c --steps 40 --warmup 4 --no-cpu-baseline > $O/prof_$c.log 2>&1
     cp $(find $O/prof_$c -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$c.csv
+    rm -rf $O/prof_$c
   done
   echo prof done
 fi
 if has pmc; then
   for c in cfg4 cfg5 cfg3; do
-    B="python3 $R/bench.py --workload $c --steps 20 --warmup 2 --no-cpu-baseline --phase-reps 2"
+    B="python3 $R/bench.py --workload $c --steps 20 --warmup 2 --regions 1 --no-cpu-baseline --phase-reps 2"
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$c -o f --output-format csv -- $B > $O/pmc_fetch_$c.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$c -o w --output-format csv -- $B > $O/pmc_write_$c.log 2>&1
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE -d $O/pmc_mfma_$c -o m --output-format csv -- $B > $O/pmc_mfma_$c.log 2>&1
     python3 $R/scripts/pmc_summary.py $c $O/pmc_fetch_$c $O/pmc_write_$c $O/pmc_mfma_$c > $O/pmc_$c.json
+    rm -rf $O/pmc_fetch_$c $O/pmc_write_$c $O/pmc_mfma_$c # (per-dispatch counter tables: tens of MB; gpurun brings back 64 MiB)
     echo pmc $c done
   done
 fi

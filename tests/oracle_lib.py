@@ -48,7 +48,7 @@ def set_wide_sums(on):
 
 
 def set_more_qr(on):
-    """MOREQR's right block QR only (ba_oracle_impl.h: solve_more_qr) instead of the LDL^T of S -- the counterpart of BA_MOREQR_QR=1."""
+    """MOREQR's right block QR only (ba_oracle_impl.h: solve_more_qr) (the default since round 4) or, on=False, the LDL^T of S -- the counterpart of BA_MOREQR_QR=0."""
     lib().ora_set_more_qr(int(bool(on)))
 
 
