@@ -88,7 +88,8 @@ def pmc_traffic(workload, kernel_name):
         return None
     if doc.get("source_sha16") != kernel_source_sha16():
         return None
-    for k, v in d.items():
+    # (several instantiations of one name -- QRKIT's level-1 and upper-level kernels --: the one that moves the most bytes per launch)
+    for k, v in sorted(d.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_fetch_x2", 0)):
         if k.split("<")[0] == kernel_name and "hbm_bytes_per_launch_fetch_x2" in v:
             return {"bytes_per_launch": v["hbm_bytes_per_launch_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_per_launch_raw"],
                     "source": "profiles/%s_pmc_%s.json (%s, FETCH_SIZE x 2 + WRITE_SIZE; sources %s)" % (PMC_ROUND, workload, k, doc["source_sha16"])}
