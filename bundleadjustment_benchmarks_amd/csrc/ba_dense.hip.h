@@ -909,6 +909,100 @@ __device__ __forceinline__ void ba_update_macro(int nrows, int ncols, int ld, in
 #endif
 }
 
+// The same macro-tile update as a kernel of its own with EIGHT waves per 128 x 128 tile (wave w: rows 64 (w >> 2), columns 32 (w & 3):
+// 2 x 4 accumulator tiles, 64 registers): two workgroups per CU are then four waves per SIMD instead of two -- twice as many
+// instruction streams whose C-tile prologue / epilogue and operand waits can hide under somebody's MFMAs (round 4's knock-outs:
+// 27.9 GB of traffic and 2.9 ms of matrix work per factorisation at D = 9216 overlap by ~1 ms in the fused form).
+// Experiment switch BA_LDLT_MACRO8=1 (ba_ldlt_factor); grid = the macro tiles of ba_macro_job, in the same order.
+template <typename T, int NB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ldlt_macro8(int nrows, int ncols, int ld, ba_macro_job<T> mj, T *__restrict__ S)
+{
+    typedef typename ba_vec2<T>::type v2;
+    constexpr int KS = 16, MT = 128, NST = 2 * NB / KS;
+    __shared__ __attribute__((aligned(16))) T As[2 * KS * MT], Bs[2 * KS * MT];
+    int u = blockIdx.x;
+    if (u >= mj.count) return;
+    const int base = mj.base, nmc = ((ncols - base + 63) / 64 + 1) / 2;
+    int mi = 0;
+    for (;; mi++) {
+        const int cnt = min(mi + 1, nmc);
+        if (u < cnt) break;
+        u -= cnt;
+    }
+    const int row0 = base + 128 * mi, col0 = base + 128 * u;
+    if (row0 >= nrows || col0 >= ncols) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wr = 64 * (wv >> 2), wc = 32 * (wv & 3);
+    const bool live = row0 + wr < nrows && col0 + wc < ncols && col0 + wc < row0 + wr + 64;
+    const int sj = 2 * (tid & 63), kq = tid >> 6; // staging: per stage and operand 2 pairs, k = kq + 8 it
+    const int ja = min(col0 + sj, ld - 2), ib = min(row0 + sj, ld - 2);
+    const int pA = mj.pM;
+    v2 ga[2], gb[2];
+    auto request = [&](int st) {
+        const int panel = st / (NB / KS), k0 = (st % (NB / KS)) * KS;
+        const T *const Lp = S + (size_t)(pA + NB * panel + k0 + kq) * ld + ja;
+        const T *const Yp = (panel ? mj.W2 : mj.W1) + (size_t)(k0 + kq) * ld + ib;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            ga[it] = *(const v2 *)(Lp + (size_t)(8 * it) * ld);
+            gb[it] = *(const v2 *)(Yp + (size_t)(8 * it) * ld);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int k = kq + 8 * it; // (k & 1) == (kq & 1)
+            const int o = buf * KS * MT + k * MT + (sj ^ (16 * (kq & 1)));
+            *(v2 *)(As + o) = ga[it];
+            *(v2 *)(Bs + o) = gb[it];
+        }
+    };
+    request(0);
+    typename ba_acc<T>::type acc[2][4];
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int uu = 0; uu < 4; uu++)
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    acc[t][uu][v] = S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * uu + li];
+    }
+    park(0);
+    __syncthreads();
+    for (int st = 0; st < NST; st++) {
+        if (st + 1 < NST) request(st + 1);
+        if (live) {
+            const T *const Ab = As + (st & 1) * KS * MT, *const Bb = Bs + (st & 1) * KS * MT;
+#pragma unroll
+            for (int q = 0; q < KS / 4; q++) {
+                const int k = 4 * q + lk, sw = 16 * (lk & 1);
+                T a[2], b[4];
+#pragma unroll
+                for (int t = 0; t < 2; t++) a[t] = Ab[k * MT + ((wc + 16 * t + li) ^ sw)];
+#pragma unroll
+                for (int uu = 0; uu < 4; uu++) b[uu] = Bb[k * MT + ((wr + 16 * uu + li) ^ sw)];
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int uu = 0; uu < 4; uu++) acc[t][uu] = ba_mfma(-a[t], b[uu], acc[t][uu]);
+            }
+        }
+        if (st + 1 < NST) park((st + 1) & 1);
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int uu = 0; uu < 4; uu++)
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                    __hip_atomic_store(&S[(size_t)(col0 + wc + 16 * t + ba_crow<T>(lk, v)) * ld + row0 + wr + 16 * uu + li], acc[t][uu][v],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Out-of-line copy for the call sites inside the panel's sub-panel loop: inlined there, the update's ~100 live
 // registers are merged into the allocation of the fully unrolled pivot loop (251 VGPRs instead of 95).
 template <typename T, int NB>
@@ -1241,9 +1335,17 @@ inline void ba_ldlt_backsweep(hipStream_t st, int ncols, int ld, int zrow, T *S,
 // workgroups), Wp: 2 * ld * NB (double-buffered Y = L D panel), Winv: one NB x NB inverse per block column.
 // safe: panel + update launches per block column (no workgroup waits for another one of its launch) -- the retry path after a
 // hand-off time-out; fault: self-test, the row workgroups of the fused steps stay silent.
+// Side stream of the factorisation (update-bound sizes): a pair's macro tiles run on st2 beside the panel step of the same block column
+// (fork / join by events: valid inside a stream capture).  All null: everything on `st`.
+struct ba_ldlt_side {
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool on() const { return st2 && ev_fork && ev_join; }
+};
+
 template <typename T, int NB>
 inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T *Wp, T *Winv, int *flags, int nflags, T *errw = nullptr,
-                           bool safe = false, int fault = 0)
+                           bool safe = false, int fault = 0, const ba_ldlt_side &side = ba_ldlt_side())
 {
     const int nblk = (ncols + NB - 1) / NB;
     const size_t wsz = (size_t)ld * NB;
@@ -1307,6 +1409,21 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
                     n64 = ntc > 1 ? nt - 1 : 0;
                 } else mj = {Wp + (size_t)((p - 2) % 4) * wsz, wprev, p0 - 2 * NB, p0 + NB, macro_count(p0 + NB)};
                 const int nq = below > 0 ? npanel : 0, np2 = below > 0 ? 2 * npanel : 1;
+                static const bool macro8 = getenv("BA_LDLT_MACRO8") != nullptr && atoi(getenv("BA_LDLT_MACRO8")) != 0;
+                if (macro8 && mj.count) { // experiment: the pair's macro tiles as a launch of their own, eight waves per tile
+                    ba_macro_job<T> none{nullptr, nullptr, 0, 0, 0};
+                    if (side.on()) { // the macro tiles beside the panel step (disjoint parts of S; both behind the previous step)
+                        (void)hipEventRecord(side.ev_fork, st);
+                        (void)hipStreamWaitEvent(side.st2, side.ev_fork, 0);
+                        hipLaunchKernelGGL((k_ldlt_macro8<T, NB>), dim3(mj.count), dim3(512), 0, side.st2, nrows, ncols, ld, mj, S);
+                        (void)hipEventRecord(side.ev_join, side.st2);
+                    }
+                    hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
+                                       wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, none, fault);
+                    if (side.on()) (void)hipStreamWaitEvent(st, side.ev_join, 0);
+                    else hipLaunchKernelGGL((k_ldlt_macro8<T, NB>), dim3(mj.count), dim3(512), 0, st, nrows, ncols, ld, mj, S);
+                    continue;
+                }
                 hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64 + mj.count), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
                                    wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, mj, fault);
             }

@@ -47,7 +47,15 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < reps + 1; rep++) {
         CK(hipMemcpyAsync(S, S0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
-        if (fused) ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags); // the product's launch sequence
+        if (fused) { // the product's launch sequence (BENCH_SIDE=1: a pair's macro tiles on a second stream, with BA_LDLT_MACRO8=1)
+            static ba_ldlt_side side;
+            if (getenv("BENCH_SIDE") && !side.st2) {
+                (void)hipStreamCreateWithFlags(&side.st2, hipStreamNonBlocking);
+                (void)hipEventCreateWithFlags(&side.ev_fork, hipEventDisableTiming);
+                (void)hipEventCreateWithFlags(&side.ev_join, hipEventDisableTiming);
+            }
+            ba_ldlt_factor<double, NB>(st, nrows, ncols, ld, S, Wp, Winv, flags, nflags, nullptr, false, 0, side);
+        }
         else for (int p = 0; p < nblk; p++) {
             const int p0 = p * NB, below = nrows - (p0 + NB), g = below > 0 ? (below + 63) / 64 : 1;
             hipLaunchKernelGGL((k_ldlt_panel<double, NB>), dim3(g), dim3(256), 0, st, nrows, ncols, ld, p0, S, Wp, Winv + (size_t)p * NB * NB, flags, nflags);
