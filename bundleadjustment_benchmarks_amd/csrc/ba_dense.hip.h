@@ -1412,16 +1412,17 @@ inline void ba_ldlt_factor(hipStream_t st, int nrows, int ncols, int ld, T *S, T
                 static const bool macro8 = getenv("BA_LDLT_MACRO8") != nullptr && atoi(getenv("BA_LDLT_MACRO8")) != 0;
                 if (macro8 && mj.count) { // experiment: the pair's macro tiles as a launch of their own, eight waves per tile
                     ba_macro_job<T> none{nullptr, nullptr, 0, 0, 0};
-                    if (side.on()) { // the macro tiles beside the panel step (disjoint parts of S; both behind the previous step)
-                        (void)hipEventRecord(side.ev_fork, st);
+                    // (side stream: the macro tiles beside the panel step -- disjoint parts of S, both behind the previous step; the panel
+                    // step is enqueued first so that its workgroups are placed first)
+                    if (side.on()) (void)hipEventRecord(side.ev_fork, st);
+                    hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
+                                       wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, none, fault);
+                    if (side.on()) {
                         (void)hipStreamWaitEvent(side.st2, side.ev_fork, 0);
                         hipLaunchKernelGGL((k_ldlt_macro8<T, NB>), dim3(mj.count), dim3(512), 0, side.st2, nrows, ncols, ld, mj, S);
                         (void)hipEventRecord(side.ev_join, side.st2);
-                    }
-                    hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,
-                                       wprev, Winv + (size_t)p * NB * NB, nq, flags, errw, mode, n64, none, fault);
-                    if (side.on()) (void)hipStreamWaitEvent(st, side.ev_join, 0);
-                    else hipLaunchKernelGGL((k_ldlt_macro8<T, NB>), dim3(mj.count), dim3(512), 0, st, nrows, ncols, ld, mj, S);
+                        (void)hipStreamWaitEvent(st, side.ev_join, 0);
+                    } else hipLaunchKernelGGL((k_ldlt_macro8<T, NB>), dim3(mj.count), dim3(512), 0, st, nrows, ncols, ld, mj, S);
                     continue;
                 }
                 hipLaunchKernelGGL((k_ldlt_step2<T, NB>), dim3(nq + np2 + n64 + mj.count), dim3(256), 0, st, nrows, ncols, ld, p0, np2, S, wcur,

@@ -83,11 +83,12 @@ __global__ __launch_bounds__(256) void k_qrkit_build(int K, int Ml, int D, const
         T q[6];
 #pragma unroll
         for (int m = 0; m < 6; m++) q[m] = Q[m];
+        const bool mine = obs_cam[ib] == a; // (ib == ia, or another observation of the same camera)
 #pragma unroll
         for (int c = 0; c < 9; c++)
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
-                T v = (obs_cam[ib] == a) ? Jc[(size_t)(9 * rr + c) * K + ib] : (T)0;
+                T v = mine ? Jc[(size_t)(9 * rr + c) * K + ib] : (T)0;
                 v -= q[3 * rr] * Z[3 * c] + q[3 * rr + 1] * Z[3 * c + 1] + q[3 * rr + 2] * Z[3 * c + 2];
                 colbase[(size_t)c * lda + r0 + 2 * (size_t)(ib - b) + rr] = v;
             }

@@ -794,7 +794,12 @@ template <typename T> struct Solver final : SolverBase {
     DevBuf<T> d_qAcopy, d_dbgr, d_dbg2; // BA_DBG_QRCHECK
     void launch_qrkit_solve()
     {
-        static const bool chk = getenv("BA_DBG_QRCHECK") != nullptr;
+        // BA_DBG_QRCHECK (diagnostic, step-level seam only): a copy of the matrix, and behind the solve its normal-equation residual (getter 14)
+        bool chk = getenv("BA_DBG_QRCHECK") != nullptr;
+        if (chk) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            chk = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        }
         if (chk) {
             if (!d_qAcopy.p) { (void)d_qAcopy.alloc(d_qA.n); (void)d_dbgr.alloc(q_lda); (void)d_dbg2.alloc((size_t)2 * D); }
             (void)hipMemcpyAsync(d_qAcopy.p, d_qA.p, sizeof(T) * d_qA.n, hipMemcpyDeviceToDevice, st);
