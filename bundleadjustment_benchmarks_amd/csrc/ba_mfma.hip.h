@@ -79,4 +79,42 @@ template <typename T> __device__ __forceinline__ T ba_wave_sum_all(T v)
     return ba_readlane63(v);
 }
 
+// FOUR sums over the 64 lanes at once (k_qr_chunk: the dot products of a reflector with a wave's four live columns): the first two
+// butterfly steps hand each lane ONE of the four values (lane & 3 picks it: a select pair and one quad-permute add per two values),
+// then the remaining steps run once instead of four times -- two rotations inside the row of 16 (row_ror 4, 8: they keep lane & 3),
+// v_permlane16_swap and v_permlane32_swap across the rows (gfx950) -- and lanes 0 .. 3 hold the four totals: four v_readlane.
+// Eleven cross-lane instructions instead of twenty-eight; the dependent chain is six steps either way.
+__device__ __forceinline__ float ba_swap_add(float v, bool half32)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = half32 ? __builtin_amdgcn_permlane32_swap(u, u, false, false) : __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ double ba_swap_add(double v, bool half32)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = half32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = half32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double a0 = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[0] << 32) | (unsigned)rl[0]);
+    const double a1 = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[1] << 32) | (unsigned)rl[1]);
+    return a0 + a1;
+}
+template <typename T> __device__ __forceinline__ void ba_wave_sum4_all(T (&x)[4], int lane)
+{
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const T k01 = o1 ? x[1] : x[0], s01 = o1 ? x[0] : x[1];
+    const T k23 = o1 ? x[3] : x[2], s23 = o1 ? x[2] : x[3];
+    const T r01 = k01 + __builtin_amdgcn_update_dpp((T)0, s01, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+    const T r23 = k23 + __builtin_amdgcn_update_dpp((T)0, s23, 0xB1, 0xf, 0xf, false);
+    const T kb = o2 ? r23 : r01, sb = o2 ? r01 : r23;
+    T r = kb + __builtin_amdgcn_update_dpp((T)0, sb, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]: lane l holds value l & 3 of its quad
+    r = ba_dpp_add<0x124, 0xf>(r);                                               // row_ror:4
+    r = ba_dpp_add<0x128, 0xf>(r);                                               // row_ror:8: ... of its row of 16
+    r = ba_swap_add(r, false);                                                   // rows 0 + 1, 2 + 3
+    r = ba_swap_add(r, true);                                                    // both halves
+#pragma unroll
+    for (int c = 0; c < 4; c++) x[c] = ba_readlane_dyn(r, c);
+}
+
 #endif

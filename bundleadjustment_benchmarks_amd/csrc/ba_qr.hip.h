@@ -169,13 +169,22 @@ template <typename T> __device__ __forceinline__ void ba_qr_tile_from_lds(const 
 // (BA_QR_HW_SQRT=1, diagnostic: the bare v_sqrt_f32 for beta -- round 3 saw config 3 accept no step with it; round 4's look at
 // that is in profiles/EXPERIMENTS.md 6.3)
 __device__ int ba_qr_hw_sqrt_flag = 0;
-__device__ int ba_qr_dbg_flag = 0; // diagnostic bits (BA_QR_DBG): 1 = full barrier in the step loop, 2 = agent acquire before the T factor re-reads V
-__device__ __forceinline__ float ba_qr_sqrt(float x, int hw) { return hw ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ int ba_qr_dbg_flag = 0; // diagnostic bits (BA_QR_DBG): 1 = full barrier in the step loop, 2 = agent acquire before the T factor re-reads V, 4 = one wave reduction per column, 8 = the column retired in front of the step's barrier
+// (x is a normal float here: smaller squared norms were rescaled by the caller.)  hw = 0: v_sqrt_f32 (1 ulp) + one Newton step;
+// 1: the bare instruction; 2: sqrtf (IEEE: ~40 dependent instructions, 280 cycles of every reflector step by the in-kernel stamps).
+__device__ __forceinline__ float ba_qr_sqrt(float x, int hw)
+{
+    if (hw == 2) return sqrtf(x);
+    const float y = __builtin_amdgcn_sqrtf(x);
+    if (hw == 1 || !(y > 0.0f) || !(y < __builtin_inff())) return y; // (0: the instruction flushed a denormal argument; inf: overflowed norm)
+    return fmaf(fmaf(-y, y, x), 0.5f * __builtin_amdgcn_rcpf(y), y);
+}
 __device__ __forceinline__ double ba_qr_sqrt(double x, int) { return sqrt(x); }
 // below this alpha^2 + |x|^2 a reflector's norm is formed again from entries scaled by `up` (a power of two: exact)
 template <typename T> struct ba_qr_tiny;
-template <> struct ba_qr_tiny<float> { static constexpr float s2 = 0x1p-80f, up = 0x1p60f; };
-template <> struct ba_qr_tiny<double> { static constexpr double s2 = 0x1p-900, up = 0x1p500; };
+// ... and above `big` (or overflowed: fp32 outlier observations reach 1e19 and more) from entries scaled by `dn`
+template <> struct ba_qr_tiny<float> { static constexpr float s2 = 0x1p-80f, up = 0x1p100f, down = 0x1p-100f, big = 0x1p100f, dn = 0x1p-70f, undn = 0x1p70f; }; // (entries below 2^-40: even denormal ones become normal)
+template <> struct ba_qr_tiny<double> { static constexpr double s2 = 0x1p-900, up = 0x1p500, down = 0x1p-500, big = 0x1p900, dn = 0x1p-500, undn = 0x1p500; };
 __device__ __forceinline__ float ba_qr_rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
@@ -183,6 +192,16 @@ __device__ __forceinline__ float ba_qr_rcp(float x)
 }
 __device__ __forceinline__ double ba_qr_rcp(double x) { return 1.0 / x; }
 
+#ifdef BA_QR_STAMP2 /* dev tool (scripts/bench_qr.hip): where one wave's step goes -- stamps inside form / update_from of ONE (step, wave) */
+#define BA_QR_FINE(i)                                                                                                                   \
+    do {                                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                              \
+        if (fine_now) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) ba_qr_fine[i] = (long long)t_; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    } while (0)
+#else
+#define BA_QR_FINE(i) do { } while (0)
+#endif
 #define BA_QR_CWV 8 /* waves of a k_qr_chunk workgroup (two per SIMD: one's reductions and LDS round trips hide behind the other's FMAs) */
 template <typename T, int NSB>
 __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, size_t lda, int c0, int bw, int row0, int level, long long stride, int nsb_total,
@@ -234,12 +253,19 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
     }
     // reflector of column j from this wave's register column `pos` (a compile-time position after unrolling): into the LDS buffer
     // j & 1, the column retired to memory.  (Rows l = lane + 64 e with e >= 1 lie below every pivot: j < 32.)
+#ifdef BA_QR_STAMP2
+    bool fine_now = false;
+#endif
+    T keep[RPL]; // the owner's retired column between form (in front of the step's barrier) and retire (behind it)
     auto form = [&](int pos, int j) {
+        BA_QR_FINE(0);
         const T a0 = a[0][pos][0]; // row `lane`: the only one that can be the pivot row or lie above it
         T2 p2 = {lane > j ? a0 * a0 : (T)0, a[0][pos][1] * a[0][pos][1]};
 #pragma unroll
         for (int k = 1; k < RP2; k++) p2 = __builtin_elementwise_fma(a[k][pos], a[k][pos], p2);
+        BA_QR_FINE(1);
         const T x2 = ba_wave_sum_all<T>(p2[0] + p2[1]);
+        BA_QR_FINE(2);
         const T alpha = ba_readlane_dyn(a0, j); // row j lives in lane j, e = 0 (j < 32); j is wave-uniform: v_readlane, no LDS trip
         T tj = 0, sc = 0, beta = alpha;
         if (x2 != (T)0) { // (a column that is already zero below its pivot keeps the identity reflector)
@@ -250,8 +276,13 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             // any more (round 4's self-check: 5e-2 off in one chunk of problem-21's panel 2; profiles/r04_qr_selfcheck.txt).  LAPACK's
             // dlarfg rescales such a column; so does this branch (rare, wave-uniform): the norm again from entries scaled by a power
             // of two, v = (x up) / (alpha up - beta up), beta = (beta up) / up.  A column that is zero even then keeps the identity.
-            if (s2 < ba_qr_tiny<T>::s2) {
-                up = ba_qr_tiny<T>::up;
+            // The same branch, scaling DOWN, takes a squared norm that is huge or has overflowed (fp32: outlier observations with entries of
+            // 1e19 and more; rounds 2 - 3 answered those with a NaN panel, i.e. a rejected trial).
+            T unup = (T)1; // 1 / up
+            if (s2 < ba_qr_tiny<T>::s2 || !(s2 < ba_qr_tiny<T>::big)) {
+                const bool small = s2 < ba_qr_tiny<T>::s2;
+                up = small ? ba_qr_tiny<T>::up : ba_qr_tiny<T>::dn;
+                unup = small ? ba_qr_tiny<T>::down : ba_qr_tiny<T>::undn;
                 const T y0 = a0 * up, y1 = a[0][pos][1] * up;
                 T ps = (lane > j ? y0 * y0 : (T)0) + y1 * y1;
 #pragma unroll
@@ -266,17 +297,20 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             const T nb = s2 != (T)0 ? ba_qr_sqrt(s2, hw_sqrt) : (T)0;
             // nb == 0 with s2 != 0: the bare v_sqrt_f32 (BA_QR_HW_SQRT=1) flushes a denormal argument -- round 3's "no LM step accepted"
             // at config 3 with the hardware square root: beta = 0, tau = 0 * inf = NaN (profiles/EXPERIMENTS.md 6.3).  Identity reflector.
-            if (nb != (T)0) {
+            if (nb != (T)0 && nb < (T)__builtin_inff()) { // (a norm that is zero or not finite even after rescaling leaves the identity)
                 const T bs = al > (T)0 ? -nb : nb;
-                tj = (bs - al) * ba_qr_rcp(bs);
-                sc = up * ba_qr_rcp(al - bs);
-                beta = bs * ba_qr_rcp(up);
+                const T tjn = (bs - al) * ba_qr_rcp(bs), scn = up * ba_qr_rcp(al - bs);
+                if (scn < (T)__builtin_inff() && scn > -(T)__builtin_inff()) { // (|alpha| + |x| a denormal: 1 / it overflows -- a zero column to working precision)
+                    tj = tjn;
+                    sc = scn;
+                    beta = bs * unup;
+                }
             }
         }
+        BA_QR_FINE(3);
         if (lane == 0) { taus[j] = tj; tj_s[j & 1] = tj; }
-        // the hand-over first (the others wait for it), then the column's way to memory: a masked-out element goes to a scratch word
-        // (this chunk's T block, which the tail overwrites behind a full barrier) -- a select on the address instead of a branch per element
-        T keep[RPL];
+        // the hand-over (the others wait for it); the column's way to memory follows BEHIND the step's barrier (retire): its eight
+        // stores with their address selects are 380 cycles that nobody has to wait for (in-kernel stamps, round 4)
         {
             const T ve = lane > j ? a0 * sc : (lane == j ? (T)1 : (T)0);
             vs[j & 1][lane] = ve;
@@ -288,13 +322,19 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             vs[j & 1][lane + 64 * e] = ve;
             keep[e] = ve;
         }
+        BA_QR_FINE(4);
+    };
+    // column j to memory (R entries above the pivot, beta on it, v below): a masked-out element goes to a scratch word (this chunk's T
+    // block, which the tail overwrites behind a full barrier) -- a select on the address instead of a branch per element
+    auto retire = [&](int j) {
         T *const junk = Tout + (size_t)g * (BA_QR_PB * BA_QR_PB) + lane;
 #pragma unroll
         for (int e = 0; e < RPL; e++) {
             const int l = lane + 64 * e;
             T *dst = (l < rows && (level == 1 || (l & 31) <= j)) ? A + (size_t)(c0 + j) * lda + grow[e] : junk;
-            *dst = keep[e]; // retire column j
+            *dst = keep[e];
         }
+        BA_QR_FINE(5);
     };
     // w_c = tau (v . a_c), a_c -= v w_c for the register columns q0 .. CW - 1 (v is 1 on its pivot row, zero above): all dot products
     // first, then all wave reductions, then the updates -- the DPP chains of the columns interleave
@@ -307,14 +347,28 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             for (int k = 1; k < RP2; k++) d2 = __builtin_elementwise_fma(v[k], a[k][q], d2);
             pd[q] = d2[0] + d2[1];
         }
+        BA_QR_FINE(8);
+        static_assert(CW == 4, "ba_wave_sum4_all reduces the four register columns of a wave");
+        {
+            T pv[4];
 #pragma unroll
-        for (int q = q0; q < CW; q++) pd[q] = tj * ba_wave_sum_all<T>(pd[q]);
+            for (int q = 0; q < CW; q++) pv[q] = q >= q0 ? pd[q] : (T)0;
+            if (dbg_bits & 4) { // (diagnostic: one reduction per column, as before round 4)
+#pragma unroll
+                for (int q = 0; q < CW; q++) pv[q] = ba_wave_sum_all<T>(pv[q]);
+            } else
+                ba_wave_sum4_all<T>(pv, lane); // the dot products of all live columns in one batched wave reduction
+#pragma unroll
+            for (int q = q0; q < CW; q++) pd[q] = tj * pv[q];
+        }
+        BA_QR_FINE(9);
 #pragma unroll
         for (int q = q0; q < CW; q++) {
             const T2 npd = {-pd[q], -pd[q]};
 #pragma unroll
             for (int k = 0; k < RP2; k++) a[k][q] = __builtin_elementwise_fma(v[k], npd, a[k][q]);
         }
+        BA_QR_FINE(10);
     };
     // In-kernel stamps (scripts/bench_qr.hip -DBA_QR_STAMP, one-workgroup launch): 1.5 - 2.0 k cycles per step at 512 rows, of which a
     // wave's update of its 3 - 4 live columns is 900 - 1400 (two waves share a SIMD's vector unit; 27 dependent-ish instructions per
@@ -328,7 +382,10 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
         for (int jw = 0; jw < NW; jw++) {
             const int j = NW * jq + jw;
             if (j >= bw) break;            // (uniform; only the last panel is narrower than 32)
-            if (jw == wv) form(jq, j);     // (wave-uniform) this wave's column jq is column j
+#ifdef BA_QR_STAMP2
+            fine_now = nch == 1 && j == 8 && (wv == 0 || wv == 5); // wave 0 owns column 8 (form), wave 5 updates three columns
+#endif
+            if (jw == wv) { form(jq, j); if (dbg_bits & 8) retire(j); } // (wave-uniform) this wave's column jq is column j
             // LDS-only barrier: the hand-over goes through LDS; __syncthreads() would also wait for the owner's global stores of the
             // retired column
             if (dbg_bits & 1) __syncthreads();
@@ -337,10 +394,16 @@ __global__ __launch_bounds__(64 * BA_QR_CWV) void k_qr_chunk(T *__restrict__ A, 
             long long t_exit = 0;
             if (nch == 1) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); t_exit = (long long)t_; if (threadIdx.x == 0) ba_qr_stamp[j] = t_exit; }
 #endif
+            if (jw == wv && !(dbg_bits & 8)) retire(j);
+#ifdef BA_QR_STAMP2
+            if (wv != 5) fine_now = false;
+#endif
+            BA_QR_FINE(6);
             const T tj = tj_s[j & 1];
             T2 v[RP2];
 #pragma unroll
             for (int k = 0; k < RP2; k++) { v[k][0] = vs[j & 1][lane + 128 * k]; v[k][1] = vs[j & 1][lane + 128 * k + 64]; }
+            BA_QR_FINE(7);
             if (wv > jw) update_from(jq, v, tj);              // column NW jq + wv > j: register columns jq .. CW - 1 are live
             else if (jq + 1 < CW) update_from(jq + 1, v, tj); // column jq of this wave is retired (or being retired)
 #ifdef BA_QR_STAMP

@@ -394,7 +394,7 @@ template <typename T> struct Solver final : SolverBase {
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_dbg_flag), &bits, sizeof(int)));
             }
             if (const char *ev = getenv("BA_QR_HW_SQRT")) { // diagnostic switch (ba_qr.hip.h: ba_qr_sqrt)
-                const int on = atoi(ev) != 0;
+                const int on = atoi(ev); // 0 (default): v_sqrt_f32 + one Newton step, 1: the bare instruction, 2: sqrtf
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ba_qr_hw_sqrt_flag), &on, sizeof(int)));
             }
             // J2bot is dense: (2K + 3M + D) x (D + 1) scalars (config 3: 256 MB in fp32; a problem whose J2bot does not fit is refused)

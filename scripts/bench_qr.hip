@@ -3,6 +3,9 @@
 // usage: bench_qr.bin [m = 181633] [n = 351]   (config 3's J2bot; fp32)
 #include "ba_mfma.hip.h"
 #define BA_REC 32 /* (ba_kernels.hip.h: scalars per observation record; only k_qrkit_build, unused here, needs it) */
+#ifdef BA_QR_STAMP2
+__device__ long long ba_qr_fine[16];
+#endif
 #ifdef BA_QR_STAMP
 __device__ long long ba_qr_stamp[40];
 __device__ long long ba_qr_busy[8 * 32]; // [step][wave]: cycles from the barrier exit to the end of the wave's work of that step // wave 0 of the one-workgroup launch of a panel: time at every step's barrier exit, then the end
@@ -55,6 +58,12 @@ int main(int argc, char **argv)
     for (int c = 0; c < n; c++) { double a = 0, b = 0; for (int i = 0; i < m; i++) { a += (double)h[(size_t)c * lda + i] * r[i]; b += (double)h[(size_t)c * lda + i] * h[(size_t)n * lda + i]; } gn += a * a; g0n += b * b; }
     printf("QR %d x %d fp32: %.3f ms per factorisation + solve = %.1f TFLOP/s; |A'(Ay-b)| / |A'b| = %.2e\n", m, n, tot / reps, 2.0 * m * n * n / (tot / reps * 1e-3) / 1e12,
            std::sqrt(gn / g0n));
+#ifdef BA_QR_STAMP2
+    { long long hf[16]; CK(hipMemcpyFromSymbol(hf, HIP_SYMBOL(ba_qr_fine), sizeof(hf)));
+      printf("last one-workgroup chunk launch, step 8.  owner (wave 0): sum of squares %lld, wave reduction %lld, scalars (sqrt, reciprocals) %lld, v to LDS %lld, column to memory %lld cycles\n",
+             hf[1] - hf[0], hf[2] - hf[1], hf[3] - hf[2], hf[4] - hf[3], hf[5] - hf[4]);
+      printf("wave 5 (three live columns): v from LDS %lld, dot products %lld, three wave reductions %lld, updates %lld cycles\n", hf[7] - hf[6], hf[8] - hf[7], hf[9] - hf[8], hf[10] - hf[9]); }
+#endif
 #ifdef BA_QR_STAMP
     long long hs[40]; CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ba_qr_stamp), sizeof(hs)));
     printf("last one-workgroup chunk launch, wave 0: cycles from kernel start to the exit of the barrier of step j, j = 0 .. 31, then loop end, then kernel end:\n");

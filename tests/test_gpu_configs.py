@@ -215,26 +215,28 @@ def test_cfg3_reflector_of_a_column_with_a_denormal_norm(ba, gpu_ok, prob39, mon
     stepped around it.  The cause (round 4, scripts/diag_hw_sqrt.py): problem-39's k1 columns hold entries of ~1e-21 in some 1024-row
     chunks; their SQUARED norm is a denormal float, which sqrtf maps to a normal number and v_sqrt_f32 flushes to zero -- beta = 0,
     tau = 0 * inf = NaN, and NaN in every later column of the panel (first: column 70).  Not a knife edge of the algorithm: a missing
-    guard.  k_qr_chunk now treats sqrt(...) == 0 like a zero column (identity reflector), and BA_QR_HW_SQRT=1 -- the diagnostic switch
-    that puts the bare instruction back -- must give the same first step to float precision and the same accept decisions."""
+    guard.  k_qr_chunk now forms the norm of such a column from rescaled entries (and treats sqrt(...) == 0 like a zero column), so the
+    square root's flavour no longer matters: the default (v_sqrt_f32 + one Newton step), BA_QR_HW_SQRT=1 (the bare instruction) and
+    BA_QR_HW_SQRT=2 (IEEE sqrtf, rounds 2 - 3's) must give the same first step to float precision and the same accept decisions."""
     ref = ba.Solver(prob39, ba.QRKIT, ba.F32)
     e0, dmax = ref.linearize()
     et0, _, dn0 = ref.try_step(1e-12 * dmax)
     r0 = ref.minimize(max_trials=6)["trace"]
     del ref
-    monkeypatch.setenv("BA_QR_HW_SQRT", "1")
     try:
-        s = ba.Solver(prob39, ba.QRKIT, ba.F32)
-        e1, _ = s.linearize()
-        et1, _, dn1 = s.try_step(1e-12 * dmax)
-        r1 = s.minimize(max_trials=6)["trace"]
-        del s
+        for flavour in ("1", "2"):
+            monkeypatch.setenv("BA_QR_HW_SQRT", flavour)
+            s = ba.Solver(prob39, ba.QRKIT, ba.F32)
+            e1, _ = s.linearize()
+            et1, _, dn1 = s.try_step(1e-12 * dmax)
+            r1 = s.minimize(max_trials=6)["trace"]
+            del s
+            assert np.isfinite(et1) and np.isfinite(dn1) and e1 == e0
+            assert abs(et1 - et0) < 1e-4 * et0 and abs(dn1 - dn0) < 1e-3 * dn0, (flavour, et0, et1, dn0, dn1)
+            assert np.array_equal(r1[:, 1], r0[:, 1]) and r1[:, 1].sum() >= 4, flavour
     finally:
         monkeypatch.setenv("BA_QR_HW_SQRT", "0")
-        ba.Solver(prob39, ba.QRKIT, ba.F32)  # (the switch is a device-side flag of the library, written at solver creation: back to sqrtf)
-    assert np.isfinite(et1) and np.isfinite(dn1) and e1 == e0
-    assert abs(et1 - et0) < 1e-4 * et0 and abs(dn1 - dn0) < 1e-3 * dn0, (et0, et1, dn0, dn1)
-    assert np.array_equal(r1[:, 1], r0[:, 1]) and r1[:, 1].sum() >= 4
+        ba.Solver(prob39, ba.QRKIT, ba.F32)  # (the switch is a device-side flag of the library, written at solver creation: back to the default)
 
 
 # ---- production loop across rejected trials ------------------------------------------------------------------------

@@ -188,7 +188,12 @@ def test_fp32_qrkit_is_as_close_to_quad_as_the_fp32_oracle(ba, O, gpu_ok):
             lam *= inc
             inc = inc ** 1.5
         lam = float(np.float32(lam))
-    pick = own[::3]
+    # (a float trajectory can run into a state whose Jacobian is not finite -- an observation's squared error overflows once its point has
+    # drifted onto the camera's plane; every later trial is then NaN = rejected, like in the reference's own float arithmetic, DESIGN.md
+    # section 2: the comparison uses the trials in front of that)
+    finite = [w for w in own if np.isfinite(w[2])]
+    assert len(finite) >= 6, len(finite)
+    pick = finite[::3] if len(finite) >= 18 else finite[::2]
     import multiprocessing as mp
     with mp.get_context("spawn").Pool(min(8, len(pick))) as pool:
         sides = pool.map(_fp32_sides, [(x, lam) for x, lam, _ in pick])
