@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void ba_bufload3(__amdgpu_buffer_rsrc_t r, unsigned o
 // where the grid runs two workgroups per CU (records beyond the Infinity Cache: 256 registers per wavefront are there) the batches
 // are twice or four times as deep.
 template <typename T, bool SCALED /* dinv != 1: CHOLESKY */, int KO = 0, int GB = 2>
-__global__ __launch_bounds__(256) void k_schur_pairs(const int *__restrict__ wave_ptr, int nband, const int4 *__restrict__ chunk_info,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GB == 2 ? 4 : 1))) void k_schur_pairs(const int *__restrict__ wave_ptr, int nband, const int4 *__restrict__ chunk_info,
                                                      const int2 *__restrict__ ent, const T *__restrict__ rec, unsigned rec_bytes,
                                                      const T *__restrict__ tvec, int Ml, T *__restrict__ slab, const T *__restrict__ V,
                                                      const T *__restrict__ gc, int D, int ld, T *__restrict__ S)
