@@ -60,6 +60,7 @@ int ora_max_threads(void) { return 1; }
 
 #define S double
 #define FN(name) CAT(name, _f64)
+#define MINNORMAL 2.2250738585072014e-308 /* DBL_MIN */
 #define SQRT sqrt
 #define FABS fabs
 #define SIN sin
@@ -68,6 +69,7 @@ int ora_max_threads(void) { return 1; }
 #include "ba_oracle_impl.h"
 #undef S
 #undef FN
+#undef MINNORMAL
 #undef SQRT
 #undef FABS
 #undef SIN
@@ -76,6 +78,7 @@ int ora_max_threads(void) { return 1; }
 
 #define S float
 #define FN(name) CAT(name, _f32)
+#define MINNORMAL 1.17549435e-38f /* FLT_MIN */
 #define SQRT sqrtf
 #define FABS fabsf
 #define SIN sinf

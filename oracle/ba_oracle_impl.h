@@ -366,7 +366,11 @@ static int FN(dense_qr_factor_tsqr)(size_t m, int n, const S *A, const S *b, S *
                 S xn = 0;
                 for (size_t i = j + 1; i < mr; i++) xn += col[i] * col[i];
                 const S alpha = col[j];
-                if (xn == 0) continue; /* H = I */
+                /* H = I for a tail that is zero -- or whose squared norm is not a normal number: Eigen's makeHouseholder
+                 * (Eigen/src/Householder/Householder.h, the library the reference's QR classes are built on; not vendored) sets
+                 * tau = 0, beta = c0 when tailSqNorm <= numeric_limits<Scalar>::min().  A sum of denormal squares has only a few
+                 * bits, and beta, tau formed from it would not fit v (what round 4 found in the GPU's kernels). */
+                if (xn <= MINNORMAL) continue;
                 S beta = SQRT(alpha * alpha + xn);
                 if (alpha > 0) beta = -beta;
                 const S tau = (beta - alpha) / beta;

@@ -24,6 +24,7 @@
 
 #define S __float128
 #define FN(name) CAT(name, _f128)
+#define MINNORMAL 3.3621031431120935062626778173217526e-4932Q /* FLT128_MIN */
 #define SQRT sqrtq
 #define FABS fabsq
 #define SIN sinq
@@ -227,6 +228,7 @@ int ref_minimize(int kind, int N, int M, int K, const int *cam_idx, const int *p
  * rounding noise of its linear solves?  (tests/golden/make_referee.py: ensemble_*_x87) */
 #undef S
 #undef FN
+#undef MINNORMAL
 #undef SQRT
 #undef FABS
 #undef SIN
@@ -234,6 +236,7 @@ int ref_minimize(int kind, int N, int M, int K, const int *cam_idx, const int *p
 #undef POW
 #define S long double
 #define FN(name) CAT(name, _f80)
+#define MINNORMAL 3.36210314311209350626e-4932L /* LDBL_MIN */
 #define SQRT sqrtl
 #define FABS fabsl
 #define SIN sinl
